@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Mint golden vectors for the DIGAT hot path by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the reference's
+``graphEncoders.py`` / ``evaluate.py`` unchanged, feeds them the synthetic MIND-shaped inputs of
+``digat_amd.synthetic`` and stores inputs/outputs as small ``.npz`` fixtures under
+``tests/golden/``.  Only data is written: no reference source, bytecode or text.
+
+Three modules the reference imports are not installable here (no network) and are stubbed in
+``sys.modules`` before the import:
+  * ``torchtext.vocab.GloVe``, ``sentence_transformers.SentenceTransformer`` — only pulled in
+    transitively (config.py:7-8 -> MIND_corpus.py:8-9 -> construct_SAG.py:4); never called.
+  * ``torch_scatter`` — ``scatter_softmax`` / ``scatter_sum`` (graphEncoders.py:7,129,130) are
+    replaced by a deliberately naive per-segment loop written from the library's documented
+    semantics (max-shifted exp, segment sum, empty segment -> 0).  The reference has no test that
+    pins this boundary, so this stub *defines* it; the oracle's vectorised version is
+    cross-checked against the same naive loop in tests/.
+
+Usage:  python oracle/make_golden.py            (rewrites every fixture, deterministic)
+"""
+from __future__ import annotations
+
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+GOLDEN = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from digat_amd import synthetic  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------------
+# reference import harness
+# --------------------------------------------------------------------------------------------
+def _naive_scatter_softmax(src, index, dim=-1, eps=1e-12):
+    assert dim in (1, -1) and src.dim() == 2
+    out = torch.zeros_like(src)
+    for b in range(src.shape[0]):
+        for s in index[b].unique().tolist():
+            sel = (index[b] == s).nonzero().flatten()
+            v = src[b, sel]
+            e = (v - v.max()).exp()
+            out[b, sel] = e / e.sum()
+    return out
+
+
+def _naive_scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+    assert dim == 1 and src.dim() == 3
+    res = torch.zeros((src.shape[0], dim_size, src.shape[2]), dtype=src.dtype)
+    for b in range(src.shape[0]):
+        for t in range(src.shape[1]):          # sequential in t, like the CPU scatter_add
+            res[b, int(index[b, t])] = res[b, int(index[b, t])] + src[b, t]
+    return res
+
+
+def import_reference():
+    if not os.path.isdir(REFERENCE):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    tt = types.ModuleType("torchtext")
+    ttv = types.ModuleType("torchtext.vocab")
+    ttv.GloVe = object
+    tt.vocab = ttv
+    st = types.ModuleType("sentence_transformers")
+    st.SentenceTransformer = object
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_softmax = _naive_scatter_softmax
+    ts.scatter_sum = _naive_scatter_sum
+    sys.modules.update({"torchtext": tt, "torchtext.vocab": ttv, "sentence_transformers": st,
+                        "torch_scatter": ts})
+    sys.path.insert(0, REFERENCE)
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        import graphEncoders  # noqa
+        import evaluate       # noqa
+    finally:
+        sys.argv = argv
+    return graphEncoders, evaluate
+
+
+def reference_encoder(graphEncoders, N, H, C, d, L, state, dropout=0.0):
+    cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C,
+                                graph_depth=L, dropout_rate=dropout)
+    enc = graphEncoders.DIGAT(cfg, d)
+    enc.initialize()
+    missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return enc.eval()
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **arrays):
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {os.path.relpath(path, REPO)}  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def checksum(batch, state):
+    tot = 0.0
+    for v in list(batch.values()) + list(state.values()):
+        tot += float(np.asarray(v, dtype=np.float64).sum())
+    return np.float64(tot)
+
+
+def run_all_functions(enc, batch, L):
+    """Outputs of every function on the path, eval mode."""
+    b = {k: T(v) for k, v in batch.items()}
+    H = b["user_news_embedding"].shape[1]
+    out = {}
+    with torch.no_grad():
+        Xn, An, Mn = b["news_graph_embeddings"], b["news_graph"], b["news_graph_mask"]
+        Au, cm, ci = b["user_graph"], b["user_category_mask"], b["user_category_indices"]
+        Xu = torch.cat([b["user_news_embedding"],
+                        enc.topic_node_embedding.unsqueeze(0).expand(Xn.shape[0], -1, -1)], dim=1)
+        c_n0 = enc.compute_news_graph_context(Xn, Mn)                       # a3
+        c_u0 = enc.compute_user_graph_context(Xu, cm, ci, c_n0)             # a4
+        out["a3_news_ctx"] = c_n0.numpy()
+        out["a4_user_ctx"] = c_u0.numpy()
+        out["a6_sdpa_candidate"] = enc.candidate_attention(Xn, Xn[:, 0], mask=Mn).numpy()   # a6
+        out["a1_news_emb_l0"] = enc.compute_news_graph_embeddings(0, Xn, An, c_u0).numpy()  # a1
+        out["a2_user_emb_l0"] = enc.compute_user_graph_embeddings(0, Xu, Au, c_n0).numpy()  # a2
+        fn, fu = enc.forward(Xn, An, Mn, b["user_news_embedding"], Au, cm, ci)              # a5
+        out["a5_forward_news"], out["a5_forward_user"] = fn.numpy(), fu.numpy()
+        inn, inu = enc.inference(Xn, An, Mn, b["user_news_embedding"], Au, cm, ci, c_n0)
+        out["a5_inference_news"], out["a5_inference_user"] = inn.numpy(), inu.numpy()
+        out["h1_logits"] = (inu * inn).sum(dim=1).numpy()                                   # model.py:89
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------------
+def fixture_tiny(ge):
+    """(i) BASELINE configs[0]: B=4, neighbors 3 / hops 1 -> N=4, H=10, C=5, d=64, L=1."""
+    B, N, H, C, d, L = 4, 4, 10, 5, 64, 1
+    state = synthetic.make_state_dict(d, C, L, seed=11, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=12)
+    enc = reference_encoder(ge, N, H, C, d, L, state)
+    out = run_all_functions(enc, batch, L)
+    save("tiny.npz", meta=np.array([B, N, H, C, d, L]),
+         **{"in_" + k: v for k, v in batch.items()}, **{"w_" + k: v for k, v in state.items()},
+         **{"out_" + k: v for k, v in out.items()})
+
+
+def fixture_default(ge):
+    """(ii) MIND-small default shape, one batch B=8: N=10, U=67, d=400, L=3.  Inputs and weights
+    are regenerated from seeds (make_encoder_batch / make_state_dict); only outputs are stored."""
+    for tag, (B, N, L, seed) in {"default_b8": (8, 10, 3, 21), "stress_b2": (2, 65, 7, 23),
+                                 "codedefault_b4": (4, 26, 3, 25)}.items():
+        H, C, d = 50, 17, 400
+        state = synthetic.make_state_dict(d, C, L, seed=seed, bias_std=0.05)
+        batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=seed + 1)
+        enc = reference_encoder(ge, N, H, C, d, L, state)
+        out = run_all_functions(enc, batch, L)
+        save(f"{tag}.npz", meta=np.array([B, N, H, C, d, L]), seeds=np.array([seed, seed + 1]),
+             input_checksum=checksum(batch, state), **{"out_" + k: v for k, v in out.items()})
+
+
+def fixture_edges(ge):
+    """(iii) E1-E5: fully-masked news rows, empty histories, single-category histories, padded-only
+    nodes, and adjacency rows with no edge at all (not produced by the reference's data prep, but
+    the -1e9 fill gives them a defined uniform result the kernels must reproduce)."""
+    B, N, H, C, d, L = 6, 10, 12, 4, 32, 2
+    state = synthetic.make_state_dict(d, C, L, seed=31, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=32, empty_history_rows=(1, 4),
+                                         isolated_news_rows=(2, 4))
+    # row 3: every history item in one category
+    hist_len = np.full(B, H, dtype=np.int64)
+    cats = np.zeros((B, H), dtype=np.int64)
+    g, cm, ci = synthetic.build_user_graphs(cats, hist_len, C)
+    batch["user_graph"][3], batch["user_category_mask"][3], batch["user_category_indices"][3] = g[3], cm[3], ci[3]
+    # row 5: adjacency rows with no edge (incl. no self loop) on both graphs, one fully-masked
+    batch["news_graph"][5, 1, :] = False
+    batch["user_graph"][5, 0, :] = False
+    batch["user_graph"][5, H + 1, :] = False
+    enc = reference_encoder(ge, N, H, C, d, L, state)
+    out = run_all_functions(enc, batch, L)
+    save("edges.npz", meta=np.array([B, N, H, C, d, L]),
+         **{"in_" + k: v for k, v in batch.items()}, **{"w_" + k: v for k, v in state.items()},
+         **{"out_" + k: v for k, v in out.items()})
+
+
+def reference_scores(enc, corpus, batch_size):
+    """util.compute_scores' flow (util.py:34-69) with the reference encoder, on the synthetic corpus."""
+    emb = T(corpus.news_embedding)
+    sa = emb.index_select(0, T(corpus.news_node_ID.astype(np.int64)).flatten()).view(
+        corpus.news_node_ID.shape[0], -1, emb.shape[1])
+    masks = T(corpus.news_graph_mask)
+    graphs = T(corpus.news_graph)
+    with torch.no_grad():
+        c_n0 = torch.cat([enc.compute_news_graph_context(sa[i:i + batch_size], masks[i:i + batch_size])
+                          for i in range(0, sa.shape[0], batch_size)])
+        scores = []
+        for s in range(0, corpus.rows, batch_size):
+            imp = T(corpus.row_impression[s:s + batch_size])
+            cand = T(corpus.row_candidate[s:s + batch_size].astype(np.int64))
+            hist = T(corpus.history.astype(np.int64)).index_select(0, imp)
+            user_rep = emb.index_select(0, hist.flatten()).view(len(imp), -1, emb.shape[1])
+            n, u = enc.inference(sa.index_select(0, cand), graphs.index_select(0, cand),
+                                 masks.index_select(0, cand), user_rep,
+                                 T(corpus.user_graph).index_select(0, imp),
+                                 T(corpus.user_category_mask).index_select(0, imp),
+                                 T(corpus.user_category_indices).index_select(0, imp),
+                                 c_n0.index_select(0, cand))
+            scores.append((u * n).sum(dim=1))
+    return torch.cat(scores).numpy(), c_n0.numpy()
+
+
+def fixture_devset(ge, ev):
+    """(iv) synthetic dev sets scored by the reference encoder, ranked by util.py:70-80's rule,
+    metrics by the reference's evaluate.scoring (sklearn AUC)."""
+    specs = {
+        "devset_tiny": synthetic.SynthSpec(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10,
+                                           category_num=5, embedding_dim=64, impressions=200,
+                                           mean_candidates=12.0, max_candidates=40, seed=41),
+        "devset_default": synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24,
+                                              mean_candidates=20.0, max_candidates=60, seed=43),
+    }
+    for tag, spec in specs.items():
+        L = 2 if tag == "devset_tiny" else 3
+        corpus = synthetic.make_corpus(spec)
+        state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=spec.seed + 1,
+                                          bias_std=0.05)
+        enc = reference_encoder(ge, spec.news_graph_size, spec.max_history_num, spec.category_num,
+                                spec.embedding_dim, L, state)
+        scores, c_n0 = reference_scores(enc, corpus, 128)
+        # util.py:70-80
+        sub = [[] for _ in range(int(corpus.row_impression[-1]) + 1)]
+        for i, imp in enumerate(corpus.row_impression.tolist()):
+            sub[imp].append([float(scores[i]), len(sub[imp])])
+        lines, truth = [], []
+        labels = [[] for _ in sub]
+        for i, imp in enumerate(corpus.row_impression.tolist()):
+            labels[imp].append(int(corpus.row_label[i]))
+        for i, s in enumerate(sub):
+            s.sort(key=lambda x: x[0], reverse=True)
+            res = [0] * len(s)
+            for j in range(len(s)):
+                res[s[j][1]] = j + 1
+            lines.append(str(i + 1) + " " + str(res).replace(" ", ""))
+            truth.append(str(i + 1) + " " + str(labels[i]).replace(" ", ""))
+        auc, mrr, n5, n10 = ev.scoring(io.StringIO("\n".join(truth)), io.StringIO("\n".join(lines)))
+        print(f"  {tag}: rows={corpus.rows} AUC={auc:.6f} MRR={mrr:.6f} nDCG5={n5:.6f} nDCG10={n10:.6f}")
+        save(f"{tag}.npz", depth=np.array(L), scores=scores.astype(np.float32),
+             c_n0_head=c_n0[:64].astype(np.float32),
+             rank_lines=np.array("\n".join(lines)), truth_lines=np.array("\n".join(truth)),
+             metrics=np.array([auc, mrr, n5, n10], dtype=np.float64),
+             input_checksum=np.float64(float(corpus.news_embedding.astype(np.float64).sum())
+                                       + float(corpus.user_graph.sum()) + float(corpus.news_graph.sum())
+                                       + float(corpus.row_candidate.astype(np.float64).sum())))
+
+
+def fixture_train_step(ge):
+    """(v) one training step, dropout 0 (so train mode is deterministic): loss of trainer.py:100,
+    gradients of every parameter and of the two embedding inputs, from the reference's autograd."""
+    B, K, N, H, C, d, L = 3, 5, 4, 10, 5, 32, 2
+    state = synthetic.make_state_dict(d, C, L, seed=51, bias_std=0.05)
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=52)
+    users = synthetic.make_encoder_batch(B, N, H, C, d, seed=53)
+    enc = reference_encoder(ge, N, H, C, d, L, state, dropout=0.0).train()
+    Xn = T(flat["news_graph_embeddings"]).requires_grad_(True)
+    ue = T(users["user_news_embedding"]).requires_grad_(True)
+
+    def expand(t):                                                          # model.py:64-71
+        return t.unsqueeze(1).expand(B, K, *t.shape[1:]).contiguous().view(B * K, *t.shape[1:])
+
+    n, u = enc(Xn, T(flat["news_graph"]), T(flat["news_graph_mask"]), expand(ue),
+               expand(T(users["user_graph"])), expand(T(users["user_category_mask"])),
+               expand(T(users["user_category_indices"])))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+    loss.backward()
+    grads = {"g_" + k: v.grad.numpy() for k, v in enc.named_parameters()}
+    save("train_step.npz", meta=np.array([B, K, N, H, C, d, L]),
+         in_news_graph_embeddings=flat["news_graph_embeddings"], in_news_graph=flat["news_graph"],
+         in_news_graph_mask=flat["news_graph_mask"], in_user_news_embedding=users["user_news_embedding"],
+         in_user_graph=users["user_graph"], in_user_category_mask=users["user_category_mask"],
+         in_user_category_indices=users["user_category_indices"],
+         **{"w_" + k: v for k, v in state.items()},
+         out_logits=logits.detach().numpy(), out_loss=loss.detach().numpy(),
+         g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    ge, ev = import_reference()
+    print("reference imported from", REFERENCE)
+    fixture_tiny(ge)
+    fixture_edges(ge)
+    fixture_train_step(ge)
+    fixture_devset(ge, ev)
+    fixture_default(ge)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""CPU suite: the oracle (oracle/digat_oracle.py) against the golden vectors minted from the
+imported reference (oracle/make_golden.py).  No GPU, no /root/reference needed.
+
+Tolerance: fp32, same ATen ops in the same order as the reference -> 1e-5 absolute / 1e-5 relative (values reach ~10 at depth 7).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, regenerate, split_fixture
+from oracle import digat_oracle as O
+
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def close(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert np.allclose(a, b, rtol=RTOL, atol=ATOL), f"{what}: max|diff|={err:.3e}"
+
+
+def run_oracle(batch, state, L):
+    p = O.as_params(state)
+    Xn, An, Mn, ue, Au, cm, ci = O.batch_tensors(batch)
+    H = ue.shape[1]
+    out = {}
+    with torch.no_grad():
+        Xu = O.user_nodes(p, ue)
+        c_n0 = O.news_graph_context(p, Xn, Mn)
+        c_u0 = O.user_graph_context(p, Xu, cm, ci, c_n0, H)
+        out["a3_news_ctx"] = c_n0
+        out["a4_user_ctx"] = c_u0
+        out["a6_sdpa_candidate"] = O.scaled_dot_attention(p, "candidate_attention", Xn, Xn[:, 0], Mn)
+        out["a1_news_emb_l0"] = O.cross_graph_attention(p, "news", 0, Xn, An, c_u0)
+        out["a2_user_emb_l0"] = O.cross_graph_attention(p, "user", 0, Xu, Au, c_n0)
+        out["a5_forward_news"], out["a5_forward_user"] = O.encoder_forward(p, L, Xn, An, Mn, ue, Au, cm, ci)
+        out["a5_inference_news"], out["a5_inference_user"] = O.encoder_inference(p, L, Xn, An, Mn, ue, Au, cm, ci, c_n0)
+        out["h1_logits"] = O.row_logits(p, L, ue, Au, cm, ci, Xn, An, Mn, c_n0)
+    return {k: v.numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["tiny.npz", "edges.npz"])
+def test_oracle_matches_reference_stored_inputs(name):
+    fx = load_golden(name)
+    ins, w, outs = split_fixture(fx)
+    L = int(fx["meta"][-1])
+    got = run_oracle(ins, w, L)
+    for k, v in outs.items():
+        close(got[k], v, f"{name}:{k}")
+
+
+@pytest.mark.parametrize("name", ["default_b8.npz", "codedefault_b4.npz", "stress_b2.npz"])
+def test_oracle_matches_reference_regenerated_inputs(name):
+    fx = load_golden(name)
+    batch, state = regenerate(fx)
+    L = int(fx["meta"][-1])
+    got = run_oracle(batch, state, L)
+    for k, v in fx.items():
+        if k.startswith("out_"):
+            close(got[k[4:]], v, f"{name}:{k}")
+
+
+def test_forward_equals_inference_in_eval():
+    fx = load_golden("tiny.npz")
+    _, _, outs = split_fixture(fx)
+    assert np.array_equal(outs["a5_forward_news"], outs["a5_inference_news"])
+    assert np.array_equal(outs["a5_forward_user"], outs["a5_inference_user"])
+
+
+def test_segment_ops_against_naive_loop():
+    rng = np.random.default_rng(5)
+    B, H, C1, d = 7, 23, 6, 9
+    a = rng.standard_normal((B, H)).astype(np.float32) * 3
+    idx = rng.integers(0, C1, size=(B, H))
+    idx[0] = 2                      # one segment holds everything
+    idx[1] = np.arange(H) % C1
+    got = O.segment_softmax(torch.from_numpy(a), torch.from_numpy(idx), C1).numpy()
+    want = O.segment_softmax_naive(a, idx, C1)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    src = rng.standard_normal((B, H, d)).astype(np.float32)
+    got = O.segment_sum(torch.from_numpy(src), torch.from_numpy(idx), C1).numpy()
+    want = np.zeros((B, C1, d), np.float32)
+    for b in range(B):
+        for t in range(H):
+            want[b, idx[b, t]] += src[b, t]
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert np.all(got[0, [0, 1, 3, 4, 5]] == 0)          # empty segments are exactly zero
+
+
+def test_fully_masked_attention_row_is_uniform():
+    """E1: -1e9 (not -inf) => an all-masked row averages every node, padded ones included."""
+    fx = load_golden("edges.npz")
+    ins, w, outs = split_fixture(fx)
+    X = ins["news_graph_embeddings"]
+    assert not ins["news_graph_mask"][2].any()
+    np.testing.assert_allclose(outs["a6_sdpa_candidate"][2], X[2].mean(axis=0), rtol=1e-5, atol=1e-6)
+
+
+def test_train_step_loss_and_gradients():
+    fx = load_golden("train_step.npz")
+    B, K, N, H, C, d, L = (int(v) for v in fx["meta"])
+    ins, w, outs = split_fixture(fx)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.as_params(w).items()}
+    Xn = torch.from_numpy(ins["news_graph_embeddings"]).view(B, K, N, d).clone().requires_grad_(True)
+    ue = torch.from_numpy(ins["user_news_embedding"]).clone().requires_grad_(True)
+    logits = O.training_logits(p, L, ue, torch.from_numpy(ins["user_graph"]),
+                               torch.from_numpy(ins["user_category_mask"]),
+                               torch.from_numpy(ins["user_category_indices"]), Xn,
+                               torch.from_numpy(ins["news_graph"]).view(B, K, N, N),
+                               torch.from_numpy(ins["news_graph_mask"]).view(B, K, N))
+    loss = O.training_loss(logits)
+    loss.backward()
+    close(logits.detach().numpy(), outs["logits"], "logits")
+    close(loss.detach().numpy(), outs["loss"], "loss")
+    close(Xn.grad.view(B * K, N, d).numpy(), fx["g_in_news_graph_embeddings"], "dX_news")
+    close(ue.grad.numpy(), fx["g_in_user_news_embedding"], "dX_user")
+    for k, v in p.items():
+        close(v.grad.numpy(), fx["g_" + k], "grad " + k)
+
+
+@pytest.mark.parametrize("name", ["devset_tiny.npz", "devset_default.npz"])
+def test_devset_scores_ranks_metrics(name):
+    from digat_amd import synthetic
+    fx = load_golden(name)
+    spec = {
+        "devset_tiny.npz": synthetic.SynthSpec(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10,
+                                               category_num=5, embedding_dim=64, impressions=200,
+                                               mean_candidates=12.0, max_candidates=40, seed=41),
+        "devset_default.npz": synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24,
+                                                  mean_candidates=20.0, max_candidates=60, seed=43),
+    }[name]
+    corpus = synthetic.make_corpus(spec)
+    L = int(fx["depth"])
+    p = O.as_params(synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L,
+                                              seed=spec.seed + 1, bias_std=0.05))
+    emb = torch.from_numpy(corpus.news_embedding)
+    ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
+    sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, emb.shape[1])
+    masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        close(c_n0[:64].numpy(), fx["c_n0_head"], "c_n0")
+        imp = torch.from_numpy(corpus.row_impression)
+        cand = torch.from_numpy(corpus.row_candidate.astype(np.int64))
+        hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+        ue = emb.index_select(0, hist.flatten()).view(len(imp), -1, emb.shape[1])
+        scores = O.row_logits(p, L, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                              torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                              torch.from_numpy(corpus.user_category_indices).index_select(0, imp),
+                              sa.index_select(0, cand), graphs.index_select(0, cand),
+                              masks.index_select(0, cand), c_n0.index_select(0, cand)).numpy()
+    np.testing.assert_allclose(scores, fx["scores"], rtol=1e-4, atol=2e-5)
+    # ranking rule + metrics restatement, fed the reference's own scores so ties cannot differ
+    ranks = O.impression_ranks(fx["scores"].tolist(), corpus.row_impression.tolist())
+    assert "\n".join(O.rank_lines(ranks)) == str(fx["rank_lines"])
+    labels = [[] for _ in ranks]
+    for i, r in zip(corpus.row_impression.tolist(), corpus.row_label.tolist()):
+        labels[i].append(int(r))
+    got = O.ranking_metrics(labels, ranks)
+    np.testing.assert_allclose(got, fx["metrics"], rtol=0, atol=1e-9)
+    # and end to end from the oracle's own scores: the repo-stated metric tolerance
+    got2 = O.ranking_metrics(labels, O.impression_ranks(scores.tolist(), corpus.row_impression.tolist()))
+    np.testing.assert_allclose(got2, fx["metrics"], rtol=0, atol=1e-4)
