@@ -1,0 +1,127 @@
+"""ctypes binding of ``libdigat_hip.so`` (the C ABI of include/digat_hip.h).
+
+The library is built in-tree by ``digat_amd/build.py`` (``hipcc --offload-arch=gfx950``).  There is
+no CPU fallback: if the shared object is missing, or a call returns a non-zero status, this module
+raises.  PyTorch only supplies device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdigat_hip.so")
+DIGAT_MAX_DEPTH = 16
+DIGAT_MAX_NODES = 128
+
+_f = C.c_void_p  # every device pointer crosses as void*
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a")]
+
+
+class Params(C.Structure):
+    _fields_ = ([("d", C.c_int32), ("depth", C.c_int32), ("category_num", C.c_int32), ("reserved", C.c_int32)]
+                + [(k, _f) for k in ("topic_node_embedding", "cand_K", "cand_Q", "cand_bQ",
+                                     "news_graph_W", "news_graph_b", "user_news_K", "user_news_Q",
+                                     "user_news_bQ", "featureAffine_W", "featureAffine_b",
+                                     "userAtt_K", "userAtt_Q", "userAtt_bQ")]
+                + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)])
+
+
+class DigatHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+_SIGNATURES = {
+    "digat_version": (C.c_int, []),
+    "digat_error_string": (C.c_char_p, [C.c_int]),
+    "digat_linear_f32": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_xattn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "digat_xattn_fwd": (C.c_int, [_f] * 12 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_xattn_pairwise_fwd": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f]),
+    "digat_news_ctx_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "digat_news_ctx_fwd": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_user_ctx_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "digat_user_ctx_fwd": (C.c_int, [_f] * 14 + [C.c_int] * 5 + [_f, C.c_size_t, _f]),
+    "digat_topic_pool_fwd": (C.c_int, [_f] * 4 + [C.c_int] * 5 + [_f]),
+    "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
+}
+EXPORTED = tuple(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DigatHipError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m digat_amd.build` or __graft_entry__.build()). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().digat_error_string(code).decode()
+        raise DigatHipError(f"{what} failed: [{code}] {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise DigatHipError("digat_amd runs on the GPU only (got a %s tensor); there is no CPU path" % dev.type)
+    for t in tensors:
+        if t.device != dev:
+            raise DigatHipError("all tensors must live on the same device")
+    return dev
+
+
+def f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise DigatHipError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def as_bytes(t: torch.Tensor) -> torch.Tensor:
+    """bool / uint8 mask -> contiguous one-byte-per-element view (no copy for torch.bool)."""
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    return (t != 0).contiguous().view(torch.uint8)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
+    """A cached scratch buffer per (device, tag), grown on demand.  Kernels launched on one stream
+    run in order, so reusing it across calls is safe."""
+    key = (device, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,957 @@
+// digat_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels for DIGAT's dual-graph
+// interaction hot path, and the C ABI declared in include/digat_hip.h.
+//
+// Kernels (DESIGN.md has the data layout and the roofline of each):
+//   gemm_f32_kernel       nn.Linear on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32),
+//                         multi-segment N (W|ffn1|ffn2 in one pass over X), fused epilogues
+//   xattn_fwd_kernel      Eq. 8: relu(K3+K1+K2).a -> leaky_relu -> -1e9 mask -> softmax_j
+//                         -> relu(alpha @ h) + X, never materialising [B,n,n,d]
+//   attn_pool_kernel      ScaledDotProductAttention with the key projection folded into the query
+//   topic_pool_kernel     torch_scatter scatter_softmax + scatter_sum over history categories
+//   build_user_nodes / row_logits   small glue kernels of DIGAT.inference / Model.inference
+//
+// gfx950 only: 64-wide wavefronts, 160 KiB LDS per CU, MFMA f32 16x16x4.  No CUDA shims.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/digat_hip.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define DIGAT_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return DIGAT_ERR_LAUNCH; \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float f4_comp(const float4& v, int s) {
+    return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// =================================================================================================
+// 1. fp32 MFMA GEMM:  y_s[M, nseg] = A[M,K] @ w_s[nseg,K]^T (+ bias_s), s < nsegs, fused epilogue
+// =================================================================================================
+enum { EPI_NONE = 0, EPI_RELU_RES = 1, EPI_GATE = 2 };
+
+struct GemmArgs {
+    const float* a0; long lda0; int k0;      // columns [0,k0) of A come from a0 ...
+    const float* a1; long lda1;              // ... columns [k0,K) from a1 (gate: [local ; global])
+    const float* w[3]; const float* bias[3]; float* y[3]; long ldy;
+    int nseg, nsegs, M, K, transW;           // transW: w_s stored [K, nseg] (y = A @ w)
+    int epi;
+    const float* e0; long lde0; const float* e1; long lde1; const float* e2; long lde2;
+    int mtiles, ntiles;
+};
+
+// LDS image: float4 tile[k4][row ^ k4]  (k4 = 4-float column group of the 32-deep K tile).
+// A lane quarter q reads column group 4*kk+q with ds_read_b128 and feeds element s of it to the
+// s-th MFMA k-step (A and B use the same k assignment, so the sum over k is complete); the XOR of
+// the low row bits makes both that read and the staging ds_write_b128 bank-conflict free.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
+    constexpr int BK4 = 8;
+    constexpr int MT = BM / WAVES_M / 16;
+    constexpr int NT = BN / WAVES_N / 16;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tile");
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "xor swizzle needs 8-row groups");
+    constexpr int A_PER_T = (BM * BK4 + 255) / 256;
+    constexpr int B_PER_T = (BN * BK4 + 255) / 256;
+    __shared__ float4 As[BK4 * BM];
+    __shared__ float4 Bs[BK4 * BN];
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles; consecutive tiles share the same rows of A (its L2 keeps them).
+    const int total = g.mtiles * g.ntiles;
+    const int chunk = (total + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int Ntot = g.nseg * g.nsegs;
+    const int ktiles = ((g.K >> 2) + BK4 - 1) / BK4;
+
+    float4 ra[A_PER_T], rb[B_PER_T];
+
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < A_PER_T; ++u) {
+            const int i = tid + u * 256;
+            float4 v = f4_zero();
+            if (i < BM * BK4) {
+                const int r = i / BK4, c4 = i % BK4;
+                const int gm = m0 + r, k = (kt * BK4 + c4) * 4;
+                if (gm < g.M && k < g.K) {
+                    const float* p = (k < g.k0) ? g.a0 + (long)gm * g.lda0 + k
+                                                : g.a1 + (long)gm * g.lda1 + (k - g.k0);
+                    v = *reinterpret_cast<const float4*>(p);
+                }
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            float4 v = f4_zero();
+            if (i < BN * BK4) {
+                const int r = g.transW ? i % BN : i / BK4;
+                const int c4 = g.transW ? i / BN : i % BK4;
+                const int gn = n0 + r, k = (kt * BK4 + c4) * 4;
+                if (gn < Ntot && k < g.K) {
+                    const int seg = gn / g.nseg, nn = gn - seg * g.nseg;
+                    const float* wp = seg == 0 ? g.w[0] : (seg == 1 ? g.w[1] : g.w[2]);
+                    if (!g.transW) {
+                        v = *reinterpret_cast<const float4*>(wp + (long)nn * g.K + k);
+                    } else {
+                        const float* p = wp + (long)k * g.nseg + nn;
+                        v = make_float4(p[0], p[g.nseg], p[2 * (long)g.nseg], p[3 * (long)g.nseg]);
+                    }
+                }
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int u = 0; u < A_PER_T; ++u) {
+            const int i = tid + u * 256;
+            if (i < BM * BK4) {
+                const int r = i / BK4, c4 = i % BK4;
+                As[c4 * BM + (r ^ c4)] = ra[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            if (i < BN * BK4) {
+                const int r = g.transW ? i % BN : i / BK4;
+                const int c4 = g.transW ? i / BN : i % BK4;
+                Bs[c4 * BN + (r ^ c4)] = rb[u];
+            }
+        }
+    };
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const bool more = kt + 1 < ktiles;
+        if (more) load_tiles(kt + 1);          // global loads fly under this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k4 = kk * 4 + (lane >> 4);
+            float4 af[MT], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * (MT * 16) + mt * 16 + (lane & 15);
+                af[mt] = As[k4 * BM + (r ^ k4)];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int r = wn * (NT * 16) + nt * 16 + (lane & 15);
+                bf[nt] = Bs[k4 * BN + (r ^ k4)];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            f4_comp(af[mt], s), f4_comp(bf[nt], s), acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[row = 4*(lane>>4) + r][col = lane&15]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int gn = n0 + wn * (NT * 16) + nt * 16 + (lane & 15);
+            if (gn >= Ntot) continue;
+            const int seg = gn / g.nseg, nn = gn - seg * g.nseg;
+            const float* bp = seg == 0 ? g.bias[0] : (seg == 1 ? g.bias[1] : g.bias[2]);
+            float* yp = seg == 0 ? g.y[0] : (seg == 1 ? g.y[1] : g.y[2]);
+            const float bv = bp ? bp[nn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
+                if (gm >= g.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (g.epi == EPI_RELU_RES) {
+                    v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
+                } else if (g.epi == EPI_GATE) {
+                    const float gate = 1.f / (1.f + expf(-v));
+                    const float loc = g.e0[(long)gm * g.lde0 + nn];
+                    const float glo = g.e1[(long)gm * g.lde1 + nn];
+                    v = gate * loc + (1.f - gate) * glo;
+                    if (g.e2) v = g.e2[(long)gm * g.lde2 + nn] + v;
+                }
+                yp[(long)gm * g.ldy + nn] = v;
+            }
+        }
+    }
+}
+
+static int launch_gemm(GemmArgs g, hipStream_t st) {
+    if (g.M <= 0) return DIGAT_OK;
+    const int Ntot = g.nseg * g.nsegs;
+    if (g.M >= 2048) {
+        g.mtiles = (g.M + 127) / 128;
+        g.ntiles = (Ntot + 79) / 80;
+        const int total = g.mtiles * g.ntiles;
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
+    } else {
+        g.mtiles = (g.M + 31) / 32;
+        g.ntiles = (Ntot + 63) / 64;
+        const int total = g.mtiles * g.ntiles;
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 64, 1, 4>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
+    }
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float* b, float* y, long ldy,
+                           int M, int N, int K, int transW) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a0 = x; g.lda0 = ldx; g.k0 = K; g.a1 = nullptr; g.lda1 = 0;
+    g.w[0] = w; g.bias[0] = b; g.y[0] = y; g.ldy = ldy;
+    g.nseg = N; g.nsegs = 1; g.M = M; g.K = K; g.transW = transW; g.epi = EPI_NONE;
+    return g;
+}
+
+// =================================================================================================
+// 2. Eq. 8 pairwise kernel (a1/a2 after the projections)
+// =================================================================================================
+// One thread owns a 4x4 tile of (centre i, neighbour j) pairs and runs the whole sum over the
+// d channels for it in registers (16 accumulators), so no cross-lane reduction is needed for the
+// scores.  P' = r + P (neighbour side, exactly the reference's K3 + K1) and Q (centre side) are
+// staged through LDS in channel chunks, double-buffered, in the image [c4][pos(node)] with
+// pos = (node%4)*NT + node/4: the 16 lanes of a ds_read_b128 group then hit consecutive 16-B
+// slots.  Scores go to LDS, one wave per row does the softmax with shuffles, and the aggregation
+// alpha @ h reads h straight from HBM/L2 (each element once per pass) with alpha broadcast from LDS.
+struct XattnArgs {
+    const float* P; const float* Q; const float* Hh; const float* X; const float* r; const float* a;
+    const uint8_t* A; float* out; float* alpha_out;
+    int B, n, d, d4;
+    int NT, NP, SN, CC4, nchunks, RB, CW, IG;
+    int stage_f4;      // float4 per operand per buffer = RB*CC4*NP
+    int am_off;        // byte offset of the adjacency bytes in LDS
+};
+constexpr int XA_NPF = 5;    // staged float4 per thread per chunk (upper bound)
+constexpr int XA_IR = 12;    // output rows per thread per aggregation pass
+
+__global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int b0 = blockIdx.x * g.RB;
+    const int rows_here = min(g.RB, g.B - b0);
+    const int n = g.n, NT = g.NT, NP = g.NP, CC4 = g.CC4, SN = g.SN, d4 = g.d4;
+
+    float4* Ps = reinterpret_cast<float4*>(smem);          // [2][stage_f4]
+    float4* Qs = Ps + 2 * g.stage_f4;                      // [2][stage_f4]
+    float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the staging buffers
+    uint8_t* Am = smem + g.am_off;                         // [RB][n*n]
+
+    // ---- phase 0: clear the staging image (pad positions must hold finite values), adjacency in
+    for (int i = tid; i < 4 * g.stage_f4; i += nthreads) Ps[i] = f4_zero();
+    {
+        const uint8_t* src = g.A + (long)b0 * n * n;
+        const int nbytes = rows_here * n * n;
+        for (int i = tid; i < nbytes; i += nthreads) Am[i] = src[i];
+    }
+
+    // per-thread staging slots: the decomposition of idx does not depend on the chunk
+    // (32-bit offsets relative to this workgroup's first row keep the register count down)
+    const int per_op = rows_here * n * CC4;
+    const float* Pblk = g.P + (long)b0 * n * g.d;
+    const float* Qblk = g.Q + (long)b0 * n * g.d;
+    const float* rblk = g.r + (long)b0 * g.d;
+    int src_off[XA_NPF];
+    int dst_off[XA_NPF];     // < 0: slot unused; bit 30: Q operand; bits 20-29: row of the block (for r)
+#pragma unroll
+    for (int u = 0; u < XA_NPF; ++u) {
+        const int idx = tid + u * nthreads;
+        dst_off[u] = -1; src_off[u] = 0;
+        if (idx < 2 * per_op) {
+            const int op = idx >= per_op;
+            const int e = idx - op * per_op;
+            const int rb = e / (n * CC4);
+            const int rem = e - rb * (n * CC4);
+            const int node = rem / CC4, c4 = rem - node * CC4;
+            src_off[u] = (rb * n + node) * g.d + c4 * 4;
+            const int pos = (node & 3) * NT + (node >> 2);
+            dst_off[u] = ((rb * CC4 + c4) * NP + pos) | (op << 30);
+        }
+    }
+    float4 pre[XA_NPF];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < XA_NPF; ++u) {
+            if (dst_off[u] >= 0) {
+                const int op = dst_off[u] >> 30;
+                const float* base = op ? Qblk : Pblk;
+                float4 v = *reinterpret_cast<const float4*>(base + src_off[u] + ch * CC4 * 4);
+                if (!op) {   // K3 + K1 first, as the reference evaluates K3 + K1 + K2
+                    const int rbn = src_off[u] / (n * g.d);
+                    const int col = src_off[u] % g.d;
+                    const float4 rv = *reinterpret_cast<const float4*>(rblk + rbn * g.d + col + ch * CC4 * 4);
+                    v = f4_add(rv, v);
+                }
+                pre[u] = v;
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < XA_NPF; ++u) {
+            if (dst_off[u] >= 0) {
+                const int op = dst_off[u] >> 30;
+                float4* dst = (op ? Qs : Ps) + buf * g.stage_f4 + (dst_off[u] & 0x3fffffff);
+                *dst = pre[u];
+            }
+        }
+    };
+
+    // ---- phase 1: scores
+    const int tiles = NT * NT;
+    const int rb_t = tid / tiles;
+    const int tt = tid - rb_t * tiles;
+    const int ti = tt / NT, tj = tt - ti * NT;
+    const bool active = rb_t < rows_here;
+
+    float acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
+
+    prefetch(0);
+    __syncthreads();            // zero fill done before the first commit
+    commit(0);
+    __syncthreads();
+    for (int ch = 0; ch < g.nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < g.nchunks;
+        if (more) prefetch(ch + 1);
+        if (active) {
+            const float4* Pb = Ps + buf * g.stage_f4 + rb_t * CC4 * NP;
+            const float4* Qb = Qs + buf * g.stage_f4 + rb_t * CC4 * NP;
+            const float4* av = reinterpret_cast<const float4*>(g.a) + ch * CC4;
+            for (int c4 = 0; c4 < CC4; ++c4) {
+                const float4 a4 = av[c4];
+                float4 p[4], q[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) p[jj] = Pb[c4 * NP + jj * NT + tj];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) q[ii] = Qb[c4 * NP + ii * NT + ti];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float s = acc[ii][jj];
+                        s = fmaf(a4.x, fmaxf(p[jj].x + q[ii].x, 0.f), s);
+                        s = fmaf(a4.y, fmaxf(p[jj].y + q[ii].y, 0.f), s);
+                        s = fmaf(a4.z, fmaxf(p[jj].z + q[ii].z, 0.f), s);
+                        s = fmaf(a4.w, fmaxf(p[jj].w + q[ii].w, 0.f), s);
+                        acc[ii][jj] = s;
+                    }
+            }
+        }
+        if (more) commit(buf ^ 1);   // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- phase 2a: leaky_relu(0.2), adjacency mask (-1e9, not -inf), scores to LDS
+    // (the barrier that ended the chunk loop makes the aliasing of Ss over the staging image safe)
+    if (active) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * ti + ii;
+            if (i >= n) continue;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * tj + jj;
+                if (j >= n) continue;
+                float e = acc[ii][jj];
+                e = e > 0.f ? e : 0.2f * e;
+                if (Am[(rb_t * n + i) * n + j] == 0) e = -1e9f;
+                Ss[(rb_t * n + i) * SN + j] = e;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2b: softmax over the neighbours j, one wave per (row, centre i)
+    for (int rho = wave; rho < rows_here * n; rho += nwaves) {
+        float* srow = Ss + (long)rho * SN;
+        const float v0 = lane < n ? srow[lane] : -INFINITY;
+        const float v1 = lane + 64 < n ? srow[lane + 64] : -INFINITY;
+        const float m = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < n ? expf(v0 - m) : 0.f;
+        const float e1 = lane + 64 < n ? expf(v1 - m) : 0.f;
+        const float inv = wave_sum(e0 + e1);
+        const float a0 = e0 / inv, a1 = e1 / inv;
+        if (lane < SN) srow[lane] = a0;                  // pad columns [n, SN) become 0
+        if (lane + 64 < SN) srow[lane + 64] = a1;
+        if (g.alpha_out) {
+            float* arow = g.alpha_out + ((long)b0 * n + rho) * n;
+            if (lane < n) arow[lane] = a0;
+            if (lane + 64 < n) arow[lane + 64] = a1;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: out_i = relu(sum_j alpha_ij h_j) + X_i
+    const int cq = tid % g.CW, ig = tid / g.CW;
+    if (ig < g.IG) {
+        for (int rb = 0; rb < rows_here; ++rb) {
+            const long brow = (long)(b0 + rb) * n;
+            const float4* H4 = reinterpret_cast<const float4*>(g.Hh) + brow * d4;
+            const float4* X4 = reinterpret_cast<const float4*>(g.X) + brow * d4;
+            float4* O4 = reinterpret_cast<float4*>(g.out) + brow * d4;
+            const float* Srb = Ss + (long)rb * n * SN;
+            for (int ibase = ig; ibase < n; ibase += g.IG * XA_IR) {
+                for (int c4 = cq; c4 < d4; c4 += g.CW) {
+                    float4 o[XA_IR];
+#pragma unroll
+                    for (int k = 0; k < XA_IR; ++k) o[k] = f4_zero();
+                    for (int j = 0; j < n; j += 4) {
+                        const float4 h0 = H4[(long)j * d4 + c4];
+                        const float4 h1 = j + 1 < n ? H4[(long)(j + 1) * d4 + c4] : f4_zero();
+                        const float4 h2 = j + 2 < n ? H4[(long)(j + 2) * d4 + c4] : f4_zero();
+                        const float4 h3 = j + 3 < n ? H4[(long)(j + 3) * d4 + c4] : f4_zero();
+#pragma unroll
+                        for (int k = 0; k < XA_IR; ++k) {
+                            const int i = ibase + k * g.IG;
+                            if (i < n) {
+                                const float4 al = *reinterpret_cast<const float4*>(Srb + i * SN + j);
+                                o[k].x = fmaf(al.w, h3.x, fmaf(al.z, h2.x, fmaf(al.y, h1.x, fmaf(al.x, h0.x, o[k].x))));
+                                o[k].y = fmaf(al.w, h3.y, fmaf(al.z, h2.y, fmaf(al.y, h1.y, fmaf(al.x, h0.y, o[k].y))));
+                                o[k].z = fmaf(al.w, h3.z, fmaf(al.z, h2.z, fmaf(al.y, h1.z, fmaf(al.x, h0.z, o[k].z))));
+                                o[k].w = fmaf(al.w, h3.w, fmaf(al.z, h2.w, fmaf(al.y, h1.w, fmaf(al.x, h0.w, o[k].w))));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < XA_IR; ++k) {
+                        const int i = ibase + k * g.IG;
+                        if (i < n) {
+                            const float4 x = X4[(long)i * d4 + c4];
+                            O4[(long)i * d4 + c4] = make_float4(fmaxf(o[k].x, 0.f) + x.x, fmaxf(o[k].y, 0.f) + x.y,
+                                                                fmaxf(o[k].z, 0.f) + x.z, fmaxf(o[k].w, 0.f) + x.w);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct XattnPlan { XattnArgs g; int threads; size_t lds; int blocks; };
+
+static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
+    if (B < 0 || n <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4 != 0 || n > DIGAT_MAX_NODES) return DIGAT_ERR_SHAPE;
+    XattnArgs& g = pl->g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.n = n; g.d = d; g.d4 = d / 4;
+    g.NT = (n + 3) / 4;
+    g.NP = 4 * g.NT + 1;
+    g.SN = (n + 3) / 4 * 4;
+    const int tiles = g.NT * g.NT;
+    int threads, rbmax;
+    if (tiles >= 128) { threads = (tiles + 63) / 64 * 64; rbmax = 1; }
+    else { threads = 256; rbmax = 256 / tiles; }
+    if (rbmax > B && B > 0) rbmax = B;
+    int bestRB = 0, bestCC = 0;
+    // 64 KiB keeps >= 2 workgroups per CU; graphs too large for that may take up to 150 KiB
+    for (int pass = 0; pass < 2 && !bestRB; ++pass) {
+    const size_t lds_budget = pass == 0 ? 64 * 1024 : 150 * 1024;
+    for (int rb = rbmax; rb >= 1 && !bestRB; --rb) {
+        int cc_ok = 0;
+        for (int cc = g.d4; cc >= 1; --cc) {
+            if (g.d4 % cc) continue;
+            if ((long)2 * rb * n * cc > (long)XA_NPF * threads) continue;
+            const size_t stage = (size_t)4 * rb * cc * g.NP * 16;
+            const size_t sc = (size_t)rb * n * g.SN * 4;
+            const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16);
+            if (tot > lds_budget) continue;
+            cc_ok = cc;
+            break;
+        }
+        const int want = g.d4 < 5 ? g.d4 : 5;
+        if (cc_ok >= want || (rb == 1 && cc_ok >= 1)) { bestRB = rb; bestCC = cc_ok; }
+    }
+    }
+    if (!bestRB) return DIGAT_ERR_SHAPE;
+    g.RB = bestRB; g.CC4 = bestCC; g.nchunks = g.d4 / g.CC4;
+    g.stage_f4 = g.RB * g.CC4 * g.NP;
+    const size_t stage = (size_t)4 * g.stage_f4 * 16;
+    const size_t sc = (size_t)g.RB * n * g.SN * 4;
+    g.am_off = (int)align_up(stage > sc ? stage : sc, 16);
+    pl->lds = g.am_off + align_up((size_t)g.RB * n * n, 16);
+    g.CW = g.d4 < threads ? g.d4 : threads;
+    g.IG = threads / g.CW;
+    pl->threads = threads;
+    pl->blocks = (B + g.RB - 1) / g.RB;
+    return DIGAT_OK;
+}
+
+static int launch_xattn_pairwise(const float* P, const float* Q, const float* h, const float* X, const float* r,
+                                 const float* a, const uint8_t* A, float* out, float* alpha_out,
+                                 int B, int n, int d, hipStream_t st) {
+    XattnPlan pl;
+    const int rc = plan_xattn(B, n, d, &pl);
+    if (rc) return rc;
+    if (B == 0) return DIGAT_OK;
+    pl.g.P = P; pl.g.Q = Q; pl.g.Hh = h; pl.g.X = X; pl.g.r = r; pl.g.a = a; pl.g.A = A;
+    pl.g.out = out; pl.g.alpha_out = alpha_out;
+    if (pl.lds > 64 * 1024) {
+        static int raised = 0;     // benign race: the attribute is idempotent
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)xattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
+            raised = 1;
+        }
+    }
+    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, pl.g);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+// =================================================================================================
+// 3. ScaledDotProductAttention pooling (a6) with the key projection folded into the query:
+//    (K x_j).q = x_j.(K^T q)  ->  one [B,d] vector kq, then a_j = x_j.kq / sqrt(d)
+// =================================================================================================
+struct PoolArgs {
+    const float* feat; long ld_b;        // feat[b] = feat + b*ld_b, nodes are d floats apart
+    const float* kq; const uint8_t* mask; const float* addend; float* out;
+    int B, n, d; float sqrt_d;
+};
+
+__global__ void __launch_bounds__(256) attn_pool_kernel(const PoolArgs g) {
+    __shared__ float sc[DIGAT_MAX_NODES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d4 = g.d >> 2, n = g.n;
+    const float4* F4 = reinterpret_cast<const float4*>(g.feat + (long)b * g.ld_b);
+    const float4* K4 = reinterpret_cast<const float4*>(g.kq + (long)b * g.d);
+    for (int j = wave; j < n; j += 4) {
+        float part = 0.f;
+        for (int c4 = lane; c4 < d4; c4 += 64) {
+            const float4 x = F4[(long)j * d4 + c4], k = K4[c4];
+            part = fmaf(x.w, k.w, fmaf(x.z, k.z, fmaf(x.y, k.y, fmaf(x.x, k.x, part))));
+        }
+        part = wave_sum(part);
+        if (lane == 0) sc[j] = g.mask[(long)b * n + j] == 0 ? -1e9f : part / g.sqrt_d;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float v0 = lane < n ? sc[lane] : -INFINITY;
+        const float v1 = lane + 64 < n ? sc[lane + 64] : -INFINITY;
+        const float m = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < n ? expf(v0 - m) : 0.f;
+        const float e1 = lane + 64 < n ? expf(v1 - m) : 0.f;
+        const float s = wave_sum(e0 + e1);
+        if (lane < n) sc[lane] = e0 / s;
+        if (lane + 64 < n) sc[lane + 64] = e1 / s;
+    }
+    __syncthreads();
+    for (int c4 = tid; c4 < d4; c4 += 256) {
+        float4 o = f4_zero();
+        for (int j = 0; j < n; ++j) {
+            const float al = sc[j];
+            const float4 x = F4[(long)j * d4 + c4];
+            o.x = fmaf(al, x.x, o.x); o.y = fmaf(al, x.y, o.y); o.z = fmaf(al, x.z, o.z); o.w = fmaf(al, x.w, o.w);
+        }
+        if (g.addend) o = f4_add(reinterpret_cast<const float4*>(g.addend + (long)b * g.d)[c4], o);
+        reinterpret_cast<float4*>(g.out + (long)b * g.d)[c4] = o;
+    }
+}
+
+static int launch_pool(const float* feat, long ld_b, const float* kq, const uint8_t* mask, const float* addend,
+                       float* out, int B, int n, int d, hipStream_t st) {
+    if (n > DIGAT_MAX_NODES || d % 4) return DIGAT_ERR_SHAPE;
+    if (B == 0) return DIGAT_OK;
+    PoolArgs g{feat, ld_b, kq, mask, addend, out, B, n, d, sqrtf((float)d)};
+    hipLaunchKernelGGL(attn_pool_kernel, dim3(B), dim3(256), 0, st, g);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+// =================================================================================================
+// 4. topic pooling: scatter_softmax over history positions grouped by category + scatter_sum
+// =================================================================================================
+struct TopicArgs {
+    const float* Xu; long ld_b; const float* kq; const int64_t* idx; float* out;
+    int B, H, C1, d; float sqrt_d;
+};
+constexpr int TOPIC_MAX_H = 256;
+
+__global__ void __launch_bounds__(256) topic_pool_kernel(const TopicArgs g) {
+    __shared__ float sa[TOPIC_MAX_H];
+    __shared__ float sal[TOPIC_MAX_H];
+    __shared__ int sidx[TOPIC_MAX_H];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d4 = g.d >> 2, H = g.H;
+    const float4* F4 = reinterpret_cast<const float4*>(g.Xu + (long)b * g.ld_b);
+    const float4* K4 = reinterpret_cast<const float4*>(g.kq + (long)b * g.d);
+    for (int t = tid; t < H; t += 256) {
+        const long v = g.idx[(long)b * H + t];
+        sidx[t] = (v >= 0 && v < g.C1) ? (int)v : -1;
+    }
+    for (int t = wave; t < H; t += 4) {
+        float part = 0.f;
+        for (int c4 = lane; c4 < d4; c4 += 64) {
+            const float4 x = F4[(long)t * d4 + c4], k = K4[c4];
+            part = fmaf(x.w, k.w, fmaf(x.z, k.z, fmaf(x.y, k.y, fmaf(x.x, k.x, part))));
+        }
+        part = wave_sum(part);
+        if (lane == 0) sa[t] = part / g.sqrt_d;
+    }
+    __syncthreads();
+    for (int t = tid; t < H; t += 256) {
+        const int s = sidx[t];
+        float m = -INFINITY;
+        for (int u = 0; u < H; ++u) if (sidx[u] == s) m = fmaxf(m, sa[u]);
+        float den = 0.f;
+        for (int u = 0; u < H; ++u) if (sidx[u] == s) den += expf(sa[u] - m);
+        sal[t] = s >= 0 ? expf(sa[t] - m) / den : 0.f;
+    }
+    __syncthreads();
+    // out[c][:] = sum over t with idx_t == c, in ascending t (the CPU scatter_add order)
+    const int total = g.C1 * d4;
+    for (int o = tid; o < total; o += 256) {
+        const int c = o / d4, c4 = o - c * d4;
+        float4 acc = f4_zero();
+        for (int t = 0; t < H; ++t) {
+            if (sidx[t] == c) {
+                const float al = sal[t];
+                const float4 x = F4[(long)t * d4 + c4];
+                acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
+                acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+            }
+        }
+        reinterpret_cast<float4*>(g.out + ((long)b * g.C1 + c) * g.d)[c4] = acc;
+    }
+}
+
+static int launch_topic(const float* Xu, long ld_b, const float* kq, const int64_t* idx, float* out,
+                        int B, int H, int C1, int d, hipStream_t st) {
+    if (H > TOPIC_MAX_H || d % 4) return DIGAT_ERR_SHAPE;
+    if (B == 0) return DIGAT_OK;
+    TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d)};
+    hipLaunchKernelGGL(topic_pool_kernel, dim3(B), dim3(256), 0, st, g);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+// =================================================================================================
+// 5. glue kernels
+// =================================================================================================
+// Xu[b] = [user_news_embedding[b] (H rows) | topic_node_embedding (C rows)]   (graphEncoders.py:191)
+__global__ void __launch_bounds__(256) build_user_nodes_kernel(const float4* ue, const float4* topic, float4* Xu,
+                                                               long B, int H, int C, int d4) {
+    const long per_row = (long)(H + C) * d4;
+    const long total = B * per_row;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / per_row;
+        const long rem = i - b * per_row;
+        const long hist = (long)H * d4;
+        Xu[i] = rem < hist ? ue[b * hist + rem] : topic[rem - hist];
+    }
+}
+
+__global__ void __launch_bounds__(256) row_logits_kernel(const float* nc, const float* uc, float* logits, int B, int d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float part = 0.f;
+    for (int c = lane; c < d; c += 64) part = fmaf(uc[(long)b * d + c], nc[(long)b * d + c], part);
+    part = wave_sum(part);
+    if (lane == 0) logits[b] = part;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int digat_version(void) { return DIGAT_ABI_VERSION; }
+
+const char* digat_error_string(int code) {
+    switch (code) {
+        case DIGAT_OK: return "ok";
+        case DIGAT_ERR_ARG: return "bad argument (null pointer or negative size)";
+        case DIGAT_ERR_SHAPE: return "unsupported shape (d % 4 != 0, graph larger than DIGAT_MAX_NODES, depth too large)";
+        case DIGAT_ERR_WORKSPACE: return "workspace too small";
+        case DIGAT_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                     int M, int N, int K, void* stream) {
+    if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
+    if (K % 4 || ldx % 4) return DIGAT_ERR_SHAPE;
+    return launch_gemm(gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0), (hipStream_t)stream);
+}
+
+// ---- a1 / a2 ------------------------------------------------------------------------------------
+size_t digat_xattn_workspace_bytes(int B, int n, int d) {
+    // h, P, Q [B,n,d] + r [B,d]
+    return align_up((size_t)3 * B * n * d * 4, 256) + align_up((size_t)B * d * 4, 256);
+}
+
+int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X, const float* r,
+                             const float* a, const uint8_t* A, float* out, float* alpha_out,
+                             int B, int n, int d, void* stream) {
+    if (!P || !Q || !h || !X || !r || !a || !A || !out) return DIGAT_ERR_ARG;
+    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha_out, B, n, d, (hipStream_t)stream);
+}
+
+int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
+                    const float* W, const float* bW, const float* F1, const float* F2,
+                    const float* F3, const float* b3, const float* a,
+                    float* out, float* alpha_out, int B, int n, int d,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !A || !ctx || !W || !F1 || !F2 || !F3 || !a || !out || !workspace) return DIGAT_ERR_ARG;
+    if (B < 0 || n <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4 || n > DIGAT_MAX_NODES) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_xattn_workspace_bytes(B, n, d)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nd = (size_t)B * n * d;
+    float* h = (float*)workspace;
+    float* P = h + nd;
+    float* Q = P + nd;
+    float* r = (float*)((char*)workspace + align_up(3 * nd * 4, 256));
+    int rc;
+    // r = ctx F3^T + b3   (K3)
+    rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
+    if (rc) return rc;
+    // [h | P | Q] = X [W | F1 | F2]^T (+ bW on h): one pass over X on the matrix cores
+    GemmArgs g = gemm_plain(X, d, W, bW, h, d, B * n, d, d, 0);
+    g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
+    g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
+    g.nsegs = 3;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha_out, B, n, d, st);
+}
+
+// ---- a3 -----------------------------------------------------------------------------------------
+size_t digat_news_ctx_workspace_bytes(int B, int N, int d) {
+    (void)N;
+    return 3 * align_up((size_t)B * d * 4, 256);
+}
+
+int digat_news_ctx_fwd(const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* bQc,
+                       const float* Wg, const float* bg, const float* addend, float* out, int B, int N, int d,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !mask || !Kc || !Qc || !Wg || !out || !workspace || B < 0 || N <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4 || N > DIGAT_MAX_NODES) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_news_ctx_workspace_bytes(B, N, d)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slot = align_up((size_t)B * d * 4, 256);
+    float* qv = (float*)workspace;
+    float* kq = (float*)((char*)workspace + slot);
+    float* glob = (float*)((char*)workspace + 2 * slot);
+    const long ldx = (long)N * d;      // node 0 of every row: the local context (graphEncoders.py:110)
+    int rc;
+    rc = launch_gemm(gemm_plain(X, ldx, Qc, bQc, qv, d, B, d, d, 0), st);           // Q(query)
+    if (rc) return rc;
+    rc = launch_gemm(gemm_plain(qv, d, Kc, nullptr, kq, d, B, d, d, 1), st);         // K^T q
+    if (rc) return rc;
+    rc = launch_pool(X, ldx, kq, mask, nullptr, glob, B, N, d, st);                  // global context
+    if (rc) return rc;
+    GemmArgs g = gemm_plain(X, ldx, Wg, bg, out, d, B, d, 2 * d, 0);                 // gate([local ; global])
+    g.k0 = d; g.a1 = glob; g.lda1 = d;
+    g.epi = EPI_GATE; g.e0 = X; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = addend; g.lde2 = d;
+    return launch_gemm(g, st);
+}
+
+// ---- a4 -----------------------------------------------------------------------------------------
+size_t digat_user_ctx_workspace_bytes(int B, int U, int H, int C1, int d) {
+    (void)U; (void)H;
+    return 2 * align_up((size_t)B * d * 4, 256) + 2 * align_up((size_t)B * C1 * d * 4, 256);
+}
+
+int digat_topic_pool_fwd(const float* Xu, const float* kq, const int64_t* cat_idx, float* out,
+                         int B, int U, int H, int C1, int d, void* stream) {
+    if (!Xu || !kq || !cat_idx || !out || B < 0 || H < 0 || U < H || C1 <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    return launch_topic(Xu, (long)U * d, kq, cat_idx, out, B, H, C1, d, (hipStream_t)stream);
+}
+
+int digat_user_ctx_fwd(const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n,
+                       const float* Ku, const float* Qu, const float* bQu, const float* Fa, const float* bFa,
+                       const float* Kua, const float* Qua, const float* bQua, const float* addend, float* out,
+                       int B, int U, int H, int C1, int d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!Xu || !cat_mask || !cat_idx || !c_n || !Ku || !Qu || !Fa || !Kua || !Qua || !out || !workspace)
+        return DIGAT_ERR_ARG;
+    if (B < 0 || H < 0 || U < H || C1 <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4 || C1 > DIGAT_MAX_NODES || H > TOPIC_MAX_H) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_user_ctx_workspace_bytes(B, U, H, C1, d)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t s1 = align_up((size_t)B * d * 4, 256), s2 = align_up((size_t)B * C1 * d * 4, 256);
+    float* qv = (float*)workspace;
+    float* kq = (float*)((char*)workspace + s1);
+    float* T = (float*)((char*)workspace + 2 * s1);
+    float* T2 = (float*)((char*)workspace + 2 * s1 + s2);
+    int rc;
+    // topic-level attention (:126-130)
+    rc = launch_gemm(gemm_plain(c_n, d, Qu, bQu, qv, d, B, d, d, 0), st);
+    if (rc) return rc;
+    rc = launch_gemm(gemm_plain(qv, d, Ku, nullptr, kq, d, B, d, d, 1), st);
+    if (rc) return rc;
+    rc = launch_topic(Xu, (long)U * d, kq, cat_idx, T, B, H, C1, d, st);
+    if (rc) return rc;
+    // featureAffine + relu + residual (:131)
+    GemmArgs g = gemm_plain(T, d, Fa, bFa, T2, d, B * C1, d, d, 0);
+    g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    // user-level attention (:133)
+    rc = launch_gemm(gemm_plain(c_n, d, Qua, bQua, qv, d, B, d, d, 0), st);
+    if (rc) return rc;
+    rc = launch_gemm(gemm_plain(qv, d, Kua, nullptr, kq, d, B, d, d, 1), st);
+    if (rc) return rc;
+    return launch_pool(T2, (long)C1 * d, kq, cat_mask, addend, out, B, C1, d, st);
+}
+
+// ---- a5 -----------------------------------------------------------------------------------------
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
+    (void)depth;
+    const int U = H + C;
+    const int nmax = N > U ? N : U;
+    size_t tot = 0;
+    tot += 2 * align_up((size_t)B * U * d * 4, 256);     // user nodes, ping-pong
+    tot += 2 * align_up((size_t)B * N * d * 4, 256);     // news nodes, ping-pong
+    tot += digat_xattn_workspace_bytes(B, nmax, d);
+    tot += max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
+    return tot;
+}
+
+int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                      const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
+                      const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
+        return DIGAT_ERR_ARG;
+    if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
+    const int d = p->d, C = p->category_num, L = p->depth, U = H + C;
+    if (d <= 0 || d % 4 || L < 0 || L > DIGAT_MAX_DEPTH || N > DIGAT_MAX_NODES || U > DIGAT_MAX_NODES || C < 0)
+        return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_encoder_workspace_bytes(B, N, H, C, d, L)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+
+    char* ws = (char*)workspace;
+    const size_t su = align_up((size_t)B * U * d * 4, 256), sn = align_up((size_t)B * N * d * 4, 256);
+    float* Xu[2] = {(float*)ws, (float*)(ws + su)};
+    ws += 2 * su;
+    float* Xn[2] = {(float*)ws, (float*)(ws + sn)};
+    ws += 2 * sn;
+    const int nmax = N > U ? N : U;
+    void* xws = ws;
+    const size_t xws_bytes = digat_xattn_workspace_bytes(B, nmax, d);
+    ws += xws_bytes;
+    void* cws = ws;
+    const size_t cws_bytes = workspace_bytes - (size_t)(ws - (char*)workspace);
+
+    int rc;
+    // user graph nodes = [history | topic nodes]  (:191)
+    {
+        const long total4 = (long)B * U * (d / 4);
+        int blocks = (int)((total4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue,
+                           (const float4*)p->topic_node_embedding, (float4*)Xu[0], (long)B, H, C, d / 4);
+        DIGAT_CHECK_LAUNCH();
+    }
+    // c_n: given (inference, :189) or computed (forward, :180); it lives in out_news from here on
+    if (c_n0) {
+        if (hipMemcpyAsync(out_news, c_n0, (size_t)B * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return DIGAT_ERR_LAUNCH;
+    } else {
+        rc = digat_news_ctx_fwd(Xn_in, Mn, p->cand_K, p->cand_Q, p->cand_bQ, p->news_graph_W, p->news_graph_b,
+                                nullptr, out_news, B, N, d, cws, cws_bytes, stream);
+        if (rc) return rc;
+    }
+    // c_u (:192)
+    rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
+                            p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
+                            nullptr, out_user, B, U, H, C + 1, d, cws, cws_bytes, stream);
+    if (rc) return rc;
+
+    const float* xn_cur = Xn_in;
+    int un = 0, nn = 0;
+    for (int i = 0; i < L; ++i) {
+        const digat_layer_params& ln = p->news[i];
+        const digat_layer_params& lu = p->user[i];
+        // both graph updates read the PREVIOUS contexts (:194-195)
+        rc = digat_xattn_fwd(xn_cur, An, out_user, ln.W, ln.bW, ln.F1, ln.F2, ln.F3, ln.b3, ln.a, Xn[nn], nullptr,
+                             B, N, d, xws, xws_bytes, stream);
+        if (rc) return rc;
+        rc = digat_xattn_fwd(Xu[un], Au, out_news, lu.W, lu.bW, lu.F1, lu.F2, lu.F3, lu.b3, lu.a, Xu[un ^ 1], nullptr,
+                             B, U, d, xws, xws_bytes, stream);
+        if (rc) return rc;
+        xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
+        // c_n += news context (:196); c_u += user context with the UPDATED c_n (:197)
+        rc = digat_news_ctx_fwd(xn_cur, Mn, p->cand_K, p->cand_Q, p->cand_bQ, p->news_graph_W, p->news_graph_b,
+                                out_news, out_news, B, N, d, cws, cws_bytes, stream);
+        if (rc) return rc;
+        rc = digat_user_ctx_fwd(Xu[un], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
+                                p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
+                                out_user, out_user, B, U, H, C + 1, d, cws, cws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DIGAT_OK;
+}
+
+int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream) {
+    if (!news_ctx || !user_ctx || !logits || B < 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (B == 0) return DIGAT_OK;
+    hipLaunchKernelGGL(row_logits_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, news_ctx, user_ctx,
+                       logits, B, d);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+}  // extern "C"

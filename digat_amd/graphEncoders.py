@@ -1,0 +1,256 @@
+"""Drop-in ``--graph_encoder=DIGAT`` plugin backed by the gfx950 HIP kernels.
+
+Mirrors the reference's class contract (graphEncoders.py:10-198): constructor
+``DIGAT(config, news_embedding_dim)`` reading ``config.{news_graph_size, max_history_num,
+category_num, graph_depth, dropout_rate}``; methods ``initialize``, ``forward`` (7 tensors),
+``inference`` (8 tensors), ``compute_news_graph_context``, ``compute_user_graph_context``,
+``compute_news_graph_embeddings``, ``compute_user_graph_embeddings``; attribute
+``max_history_num``; and the same parameter names, so reference checkpoints load and the
+trainer's ``'graph_encoder.'`` no-decay match still works.
+
+All arithmetic happens in ``libdigat_hip.so`` through the C ABI (include/digat_hip.h).  There is
+no eager / CPU fallback: tensors must be on the GPU and the extension must be built.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import ScaledDotProductAttention
+
+
+class GraphEncoder(nn.Module):
+    def __init__(self, config, news_embedding_dim: int):
+        super().__init__()
+        self.news_graph_size = config.news_graph_size
+        self.user_graph_size = config.max_history_num + config.category_num
+        self.max_history_num = config.max_history_num
+        self.category_num = config.category_num + 1          # +1: the padding bucket (E3)
+        self.news_embedding_dim = news_embedding_dim
+        self.graph_depth = config.graph_depth
+        self.dropout_rate = float(config.dropout_rate)
+        self.attention_scalar = math.sqrt(float(self.news_embedding_dim))
+        self.topic_node_embedding = nn.Parameter(torch.zeros([config.category_num, self.news_embedding_dim]))
+
+    def initialize(self):
+        nn.init.zeros_(self.topic_node_embedding)
+
+    def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                user_category_mask, user_category_indices):
+        raise Exception('Function forward must be implemented at sub-class')
+
+    def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                  user_category_mask, user_category_indices, news_graph_context):
+        raise Exception('Function inference must be implemented at sub-class')
+
+
+class DIGAT(GraphEncoder):
+    def __init__(self, config, news_embedding_dim: int):
+        super().__init__(config, news_embedding_dim)
+        d, L = self.news_embedding_dim, self.graph_depth
+        if d % 4 != 0:
+            raise ValueError("digat_amd needs news_embedding_dim % 4 == 0 (float4 rows)")
+        if L > _lib.DIGAT_MAX_DEPTH or max(self.news_graph_size, self.user_graph_size) > _lib.DIGAT_MAX_NODES:
+            raise ValueError("graph_depth <= %d and graph sizes <= %d are supported"
+                             % (_lib.DIGAT_MAX_DEPTH, _lib.DIGAT_MAX_NODES))
+        # compute_news_graph_context
+        self.candidate_attention = ScaledDotProductAttention(d, d, d)
+        self.news_graph_W = nn.Linear(d * 2, d, bias=True)
+        # compute_user_graph_context
+        self.user_news_K = nn.Linear(d, d, bias=False)
+        self.user_news_Q = nn.Linear(d, d, bias=True)
+        self.featureAffine = nn.Linear(d, d, bias=True)
+        self.userAttention = ScaledDotProductAttention(d, d, d)
+        # Eq. 8 layers
+        for g in ("news", "user"):
+            setattr(self, f"{g}_graph_attention_W", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn1", nn.ModuleList([nn.Linear(d, d, bias=False) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn2", nn.ModuleList([nn.Linear(d, d, bias=False) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn3", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_a", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
+        self._param_block = None
+
+    # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
+    def initialize(self):
+        super().initialize()
+        relu_gain = nn.init.calculate_gain('relu')
+        leaky_gain = nn.init.calculate_gain('leaky_relu', 0.2)
+        for g in ("news", "user"):
+            for i in range(self.graph_depth):
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_W")[i].weight)
+                nn.init.zeros_(getattr(self, f"{g}_graph_attention_W")[i].bias)
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_a")[i].weight, gain=leaky_gain)
+                for f in ("ffn1", "ffn2", "ffn3"):
+                    nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_{f}")[i].weight, gain=relu_gain)
+                nn.init.zeros_(getattr(self, f"{g}_graph_attention_ffn3")[i].bias)
+        self.candidate_attention.initialize()
+        nn.init.xavier_uniform_(self.news_graph_W.weight)
+        nn.init.zeros_(self.news_graph_W.bias)
+        nn.init.xavier_uniform_(self.user_news_K.weight)
+        nn.init.xavier_uniform_(self.user_news_Q.weight)
+        nn.init.zeros_(self.user_news_Q.bias)
+        nn.init.xavier_uniform_(self.featureAffine.weight, gain=relu_gain)
+        nn.init.zeros_(self.featureAffine.bias)
+        self.userAttention.initialize()
+
+    # ------------------------------------------------------------------ parameter block for the C ABI
+    def _apply(self, fn, *args, **kwargs):
+        self._param_block = None          # .cuda() / .to() move the storages
+        return super()._apply(fn, *args, **kwargs)
+
+    def _params(self) -> "_lib.Params":
+        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        if self._param_block is not None and self._param_block[0] == ptrs:
+            return self._param_block[1]
+        for p in self.parameters():
+            if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.DigatHipError("DIGAT parameters must be contiguous float32 CUDA tensors "
+                                         "(call model.cuda()); there is no CPU path")
+        P = _lib.Params()
+        P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
+        P.topic_node_embedding = self.topic_node_embedding.data_ptr()
+        P.cand_K = self.candidate_attention.K.weight.data_ptr()
+        P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
+        P.cand_bQ = self.candidate_attention.Q.bias.data_ptr()
+        P.news_graph_W = self.news_graph_W.weight.data_ptr()
+        P.news_graph_b = self.news_graph_W.bias.data_ptr()
+        P.user_news_K = self.user_news_K.weight.data_ptr()
+        P.user_news_Q = self.user_news_Q.weight.data_ptr()
+        P.user_news_bQ = self.user_news_Q.bias.data_ptr()
+        P.featureAffine_W = self.featureAffine.weight.data_ptr()
+        P.featureAffine_b = self.featureAffine.bias.data_ptr()
+        P.userAtt_K = self.userAttention.K.weight.data_ptr()
+        P.userAtt_Q = self.userAttention.Q.weight.data_ptr()
+        P.userAtt_bQ = self.userAttention.Q.bias.data_ptr()
+        for g, arr in (("news", P.news), ("user", P.user)):
+            for i in range(self.graph_depth):
+                lp = arr[i]
+                W = getattr(self, f"{g}_graph_attention_W")[i]
+                lp.W, lp.bW = W.weight.data_ptr(), W.bias.data_ptr()
+                lp.F1 = getattr(self, f"{g}_graph_attention_ffn1")[i].weight.data_ptr()
+                lp.F2 = getattr(self, f"{g}_graph_attention_ffn2")[i].weight.data_ptr()
+                F3 = getattr(self, f"{g}_graph_attention_ffn3")[i]
+                lp.F3, lp.b3 = F3.weight.data_ptr(), F3.bias.data_ptr()
+                lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
+        self._param_block = (ptrs, P)
+        return P
+
+    def _eval_only(self, what: str):
+        if self.training and self.dropout_rate > 0 and torch.is_grad_enabled():
+            raise NotImplementedError(
+                f"{what}: the HIP path implements eval-mode semantics (dropout = identity); "
+                "call model.eval() / torch.no_grad(), or train through digat_amd.training")
+
+    # ------------------------------------------------------------------ a3 (graphEncoders.py:109-114)
+    def compute_news_graph_context(self, news_graph_embeddings, news_graph_mask):
+        X = _lib.f32(news_graph_embeddings)
+        dev = _lib.require_device(X, news_graph_mask)
+        B, N, d = X.shape
+        mask = _lib.as_bytes(news_graph_mask)
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        nbytes = L.digat_news_ctx_workspace_bytes(B, N, d)
+        ws = _lib.workspace(nbytes, dev, "ctx")
+        ca, g = self.candidate_attention, self.news_graph_W
+        _lib.check(L.digat_news_ctx_fwd(X.data_ptr(), mask.data_ptr(), ca.K.weight.data_ptr(), ca.Q.weight.data_ptr(),
+                                        ca.Q.bias.data_ptr(), g.weight.data_ptr(), g.bias.data_ptr(), None,
+                                        out.data_ptr(), B, N, d, ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                   "digat_news_ctx_fwd")
+        return out
+
+    # ------------------------------------------------------------------ a4 (graphEncoders.py:123-134)
+    def compute_user_graph_context(self, user_graph_embeddings, user_category_mask, user_category_indices,
+                                   news_graph_context):
+        Xu = _lib.f32(user_graph_embeddings)
+        c_n = _lib.f32(news_graph_context)
+        dev = _lib.require_device(Xu, user_category_mask, user_category_indices, c_n)
+        B, U, d = Xu.shape
+        H, C1 = self.max_history_num, self.category_num
+        mask = _lib.as_bytes(user_category_mask)
+        idx = user_category_indices.to(torch.int64).contiguous()
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        nbytes = L.digat_user_ctx_workspace_bytes(B, U, H, C1, d)
+        ws = _lib.workspace(nbytes, dev, "ctx")
+        ua = self.userAttention
+        _lib.check(L.digat_user_ctx_fwd(Xu.data_ptr(), mask.data_ptr(), idx.data_ptr(), c_n.data_ptr(),
+                                        self.user_news_K.weight.data_ptr(), self.user_news_Q.weight.data_ptr(),
+                                        self.user_news_Q.bias.data_ptr(), self.featureAffine.weight.data_ptr(),
+                                        self.featureAffine.bias.data_ptr(), ua.K.weight.data_ptr(),
+                                        ua.Q.weight.data_ptr(), ua.Q.bias.data_ptr(), None, out.data_ptr(),
+                                        B, U, H, C1, d, ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                   "digat_user_ctx_fwd")
+        return out
+
+    # ------------------------------------------------------------------ a1 / a2 (graphEncoders.py:143-174)
+    def _xattn(self, g: str, index: int, X, A, ctx, return_alpha: bool = False):
+        X, ctx = _lib.f32(X), _lib.f32(ctx)
+        dev = _lib.require_device(X, A, ctx)
+        B, n, d = X.shape
+        adj = _lib.as_bytes(A)
+        out = torch.empty_like(X)
+        alpha = torch.empty((B, n, n), dtype=torch.float32, device=dev) if return_alpha else None
+        L = _lib.lib()
+        nbytes = L.digat_xattn_workspace_bytes(B, n, d)
+        ws = _lib.workspace(nbytes, dev, "xattn")
+        W = getattr(self, f"{g}_graph_attention_W")[index]
+        F3 = getattr(self, f"{g}_graph_attention_ffn3")[index]
+        _lib.check(L.digat_xattn_fwd(X.data_ptr(), adj.data_ptr(), ctx.data_ptr(), W.weight.data_ptr(),
+                                     W.bias.data_ptr(),
+                                     getattr(self, f"{g}_graph_attention_ffn1")[index].weight.data_ptr(),
+                                     getattr(self, f"{g}_graph_attention_ffn2")[index].weight.data_ptr(),
+                                     F3.weight.data_ptr(), F3.bias.data_ptr(),
+                                     getattr(self, f"{g}_graph_attention_a")[index].weight.data_ptr(),
+                                     out.data_ptr(), _lib.ptr(alpha), B, n, d, ws.data_ptr(), nbytes,
+                                     _lib.stream_ptr()), "digat_xattn_fwd")
+        return (out, alpha) if return_alpha else out
+
+    def compute_news_graph_embeddings(self, index, news_graph_embeddings, news_graph, user_graph_context):
+        self._eval_only("compute_news_graph_embeddings")
+        return self._xattn("news", index, news_graph_embeddings, news_graph, user_graph_context)
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph, news_graph_context):
+        self._eval_only("compute_user_graph_embeddings")
+        return self._xattn("user", index, user_graph_embeddings, user_graph, news_graph_context)
+
+    # ------------------------------------------------------------------ a5 (graphEncoders.py:177-198)
+    def _encode(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                user_category_mask, user_category_indices, news_graph_context):
+        Xn, ue = _lib.f32(news_graph_embeddings), _lib.f32(user_news_embedding)
+        dev = _lib.require_device(Xn, news_graph, news_graph_mask, ue, user_graph, user_category_mask,
+                                  user_category_indices)
+        B, N, d = Xn.shape
+        H, C = self.max_history_num, self.category_num - 1
+        if ue.shape != (B, H, d) or user_graph.shape[1] != H + C or N != self.news_graph_size:
+            raise _lib.DigatHipError("input shapes do not match the encoder's configuration")
+        An, Mn = _lib.as_bytes(news_graph), _lib.as_bytes(news_graph_mask)
+        Au, cm = _lib.as_bytes(user_graph), _lib.as_bytes(user_category_mask)
+        ci = user_category_indices.to(torch.int64).contiguous()
+        c0 = None if news_graph_context is None else _lib.f32(news_graph_context)
+        out_n = torch.empty((B, d), dtype=torch.float32, device=dev)
+        out_u = torch.empty((B, d), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        nbytes = L.digat_encoder_workspace_bytes(B, N, H, C, d, self.graph_depth)
+        ws = _lib.workspace(nbytes, dev, "encoder")
+        P = self._params()
+        _lib.check(L.digat_encoder_fwd(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
+                                       cm.data_ptr(), ci.data_ptr(), _lib.ptr(c0), out_n.data_ptr(), out_u.data_ptr(),
+                                       B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_encoder_fwd")
+        return out_n, out_u
+
+    def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                user_category_mask, user_category_indices):
+        if self.training and torch.is_grad_enabled():
+            from .training import digat_forward_train
+            return digat_forward_train(self, news_graph_embeddings, news_graph, news_graph_mask,
+                                       user_news_embedding, user_graph, user_category_mask, user_category_indices)
+        return self._encode(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                            user_category_mask, user_category_indices, None)
+
+    def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                  user_category_mask, user_category_indices, news_graph_context):
+        return self._encode(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                            user_category_mask, user_category_indices, news_graph_context)

@@ -1,0 +1,144 @@
+/*
+ * digat_hip.h — C ABI of the MI355X (gfx950) DIGAT dual-graph interaction hot path.
+ *
+ * The reference (Veason-silverbullet/DIGAT) has no FFI: its boundary for this path is the Python
+ * class contract of graphEncoders.DIGAT (graphEncoders.py:48-198), selected by
+ * `--graph_encoder=DIGAT` (model.py:18-19).  This header is the boundary a native implementation
+ * of that class binds to; every entry point names the reference function it replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to contiguous row-major data, 16-byte aligned;
+ *     fp32 unless stated; adjacency / masks are one byte per element (torch.bool), 0 = absent;
+ *     category indices are int64 (MIND_corpus.py:149);
+ *   - nn.Linear weights are [out, in] exactly as in the reference's state_dict;
+ *   - d (news_embedding_dim) must be a multiple of 4; graph sizes n <= DIGAT_MAX_NODES;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no allocation, no host sync:
+ *     scratch comes from the caller (`workspace`, size from the matching *_workspace_bytes);
+ *   - inputs are never written; outputs may alias the `addend` argument where one exists;
+ *   - returns DIGAT_OK (0) or a DIGAT_ERR_* code, never throws.  Eval-mode semantics
+ *     (dropout = identity), i.e. what DIGAT.inference / model.eval() computes.
+ */
+#ifndef DIGAT_HIP_H
+#define DIGAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIGAT_ABI_VERSION 1
+#define DIGAT_MAX_NODES 128
+#define DIGAT_MAX_DEPTH 16
+
+enum {
+    DIGAT_OK = 0,
+    DIGAT_ERR_ARG = 1,        /* null pointer / negative size */
+    DIGAT_ERR_SHAPE = 2,      /* d % 4 != 0, n > DIGAT_MAX_NODES, depth > DIGAT_MAX_DEPTH ... */
+    DIGAT_ERR_WORKSPACE = 3,  /* workspace too small */
+    DIGAT_ERR_LAUNCH = 4      /* the HIP runtime refused a launch */
+};
+
+int digat_version(void);
+const char* digat_error_string(int code);
+
+/* ---- nn.Linear on the matrix cores: y[M,N] = x[M,K] @ w[N,K]^T + b[N]  (b may be NULL) --------
+ * Replaces the aten::addmm / mm calls of graphEncoders.py:146-149,166-169 (exact fp32:
+ * v_mfma_f32_16x16x4_f32).  ldx / ldy are row strides in floats. */
+int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                     int M, int N, int K, void* stream);
+
+/* ---- a1 / a2: DIGAT.compute_news_graph_embeddings / compute_user_graph_embeddings -------------
+ * graphEncoders.py:143-154 / :163-174 (Eq. 8).  X [B,n,d], A [B,n,n] bytes, ctx [B,d] (the OTHER
+ * graph's context); W [d,d]+bW, F1 (ffn1, neighbour j), F2 (ffn2, centre i), F3 [d,d]+b3, a [d]
+ * (the [1,d] weight of *_graph_attention_a).  out [B,n,d] = relu(alpha @ h) + X.
+ * alpha_out [B,n,n] is optional (NULL to skip). */
+size_t digat_xattn_workspace_bytes(int B, int n, int d);
+int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
+                    const float* W, const float* bW, const float* F1, const float* F2,
+                    const float* F3, const float* b3, const float* a,
+                    float* out, float* alpha_out, int B, int n, int d,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* The Eq. 8 pairwise kernel alone, on already-projected inputs (h = X W^T + bW, P = X F1^T,
+ * Q = X F2^T, r = ctx F3^T + b3): score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j -> aggregate.
+ * This is the kernel bench.py prices against the HBM roofline. */
+int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X,
+                             const float* r, const float* a, const uint8_t* A,
+                             float* out, float* alpha_out, int B, int n, int d, void* stream);
+
+/* ---- a3: DIGAT.compute_news_graph_context  (graphEncoders.py:109-114, layers.py:199-206) ------
+ * X [B,N,d], mask [B,N] bytes; Kc/Qc/bQc = candidate_attention.{K.weight,Q.weight,Q.bias},
+ * Wg [d,2d]/bg = news_graph_W.  out [B,d] = addend + context (addend may be NULL or == out). */
+size_t digat_news_ctx_workspace_bytes(int B, int N, int d);
+int digat_news_ctx_fwd(const float* X, const uint8_t* mask,
+                       const float* Kc, const float* Qc, const float* bQc,
+                       const float* Wg, const float* bg,
+                       const float* addend, float* out, int B, int N, int d,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a4 (+a7): DIGAT.compute_user_graph_context  (graphEncoders.py:123-134) -------------------
+ * Xu [B,U,d] (first H nodes = history), cat_mask [B,C1] bytes, cat_idx [B,H] int64 in [0,C1),
+ * c_n [B,d].  C1 = category_num + 1.  Contains the torch_scatter scatter_softmax / scatter_sum
+ * replacement (topic pooling).  out [B,d] = addend + context. */
+size_t digat_user_ctx_workspace_bytes(int B, int U, int H, int C1, int d);
+int digat_user_ctx_fwd(const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n,
+                       const float* Ku, const float* Qu, const float* bQu,
+                       const float* Fa, const float* bFa,
+                       const float* Kua, const float* Qua, const float* bQua,
+                       const float* addend, float* out, int B, int U, int H, int C1, int d,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* topic pooling alone: out [B,C1,d] = scatter_sum(scatter_softmax(a) * hist) with
+ * a_t = hist_t . kq / sqrt(d); kq [B,d] = (c_n Qu^T + bQu) Ku.  (graphEncoders.py:126-130) */
+int digat_topic_pool_fwd(const float* Xu, const float* kq, const int64_t* cat_idx, float* out,
+                         int B, int U, int H, int C1, int d, void* stream);
+
+/* ---- a5: DIGAT.forward / DIGAT.inference  (graphEncoders.py:177-198) ---------------------------
+ * Parameter block: the reference's state_dict tensors by name (prefix graph_encoder. in Model). */
+typedef struct digat_layer_params {
+    const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */
+    const float *F1;          /* {g}_graph_attention_ffn1.i.weight        */
+    const float *F2;          /* {g}_graph_attention_ffn2.i.weight        */
+    const float *F3, *b3;     /* {g}_graph_attention_ffn3.i.{weight,bias} */
+    const float *a;           /* {g}_graph_attention_a.i.weight  [1,d]    */
+} digat_layer_params;
+
+typedef struct digat_params {
+    int32_t d;                /* news_embedding_dim                        */
+    int32_t depth;            /* graph_depth                               */
+    int32_t category_num;     /* C (topic_node_embedding rows)             */
+    int32_t reserved;
+    const float *topic_node_embedding;                      /* [C,d]        */
+    const float *cand_K, *cand_Q, *cand_bQ;                 /* candidate_attention */
+    const float *news_graph_W, *news_graph_b;               /* [d,2d], [d]  */
+    const float *user_news_K, *user_news_Q, *user_news_bQ;
+    const float *featureAffine_W, *featureAffine_b;
+    const float *userAtt_K, *userAtt_Q, *userAtt_bQ;        /* userAttention */
+    digat_layer_params news[DIGAT_MAX_DEPTH];
+    digat_layer_params user[DIGAT_MAX_DEPTH];
+} digat_params;
+
+/* news_graph_embeddings [B,N,d], news_graph [B,N,N], news_graph_mask [B,N],
+ * user_news_embedding [B,H,d], user_graph [B,U,U] (U = H + C), user_category_mask [B,C+1],
+ * user_category_indices [B,H] int64, news_graph_context [B,d] or NULL.
+ * NULL context = DIGAT.forward in eval mode (c_n0 computed here, :180); non-NULL = DIGAT.inference.
+ * Outputs: the 2-tuple (news_graph_context, user_graph_context), each [B,d]. */
+size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth);
+int digat_encoder_fwd(const digat_params* params,
+                      const float* news_graph_embeddings, const uint8_t* news_graph,
+                      const uint8_t* news_graph_mask, const float* user_news_embedding,
+                      const uint8_t* user_graph, const uint8_t* user_category_mask,
+                      const int64_t* user_category_indices, const float* news_graph_context,
+                      float* out_news_context, float* out_user_context,
+                      int B, int N, int H,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* H1: Model.inference's last line (model.py:89): logits[b] = sum_c user_ctx[b,c] * news_ctx[b,c]. */
+int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIGAT_HIP_H */
