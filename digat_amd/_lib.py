@@ -54,7 +54,10 @@ _SIGNATURES = {
     "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
+    "digat_profile_start": (C.c_int, [C.c_int]),
+    "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
+KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue")
 EXPORTED = tuple(_SIGNATURES)
 
 
@@ -111,6 +114,18 @@ def as_bytes(t: torch.Tensor) -> torch.Tensor:
     if t.dtype == torch.uint8:
         return t.contiguous()
     return (t != 0).contiguous().view(torch.uint8)
+
+
+def profile_start(max_launches: int = 1 << 16) -> None:
+    check(lib().digat_profile_start(max_launches), "digat_profile_start")
+
+
+def profile_stop():
+    """-> {kind: {"ms": total ms, "work": flops or bytes, "launches": n}}"""
+    n = len(KERNEL_KINDS)
+    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
+    check(lib().digat_profile_stop(ms, work, cnt), "digat_profile_stop")
+    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, k in enumerate(KERNEL_KINDS)}
 
 
 _workspaces = {}

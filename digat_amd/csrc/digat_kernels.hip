@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/digat_hip.h"
 
@@ -25,6 +26,29 @@ typedef float v4f __attribute__((ext_vector_type(4)));
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- optional per-kernel event timing (bench.py's roofline leg) ---------------------------------
+// Between digat_profile_start and digat_profile_stop every launch is bracketed by two hipEvents
+// recorded on the stream the kernel is launched on; stop() synchronises once and sums elapsed time
+// and the algorithmic work (flops for the MFMA kernels, bytes for the others) per kernel kind.
+static struct {
+    int enabled, cap, used;
+    hipEvent_t* ev;
+    int* kind;
+    double* work;
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr};
+
+struct ProfScope {
+    hipStream_t st; int slot;
+    ProfScope(int kind, double work, hipStream_t s) : st(s), slot(-1) {
+        if (g_prof.enabled && g_prof.used < g_prof.cap) {
+            slot = g_prof.used++;
+            g_prof.kind[slot] = kind; g_prof.work[slot] = work;
+            hipEventRecord(g_prof.ev[2 * slot], st);
+        }
+    }
+    ~ProfScope() { if (slot >= 0) hipEventRecord(g_prof.ev[2 * slot + 1], st); }
+};
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
@@ -223,9 +247,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-static int launch_gemm(GemmArgs g, hipStream_t st) {
+static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
+    ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.M >= 2048) {
         g.mtiles = (g.M + 127) / 128;
         g.ntiles = (Ntot + 79) / 80;
@@ -539,6 +564,8 @@ static int launch_xattn_pairwise(const float* P, const float* Q, const float* h,
     if (B == 0) return DIGAT_OK;
     pl.g.P = P; pl.g.Q = Q; pl.g.Hh = h; pl.g.X = X; pl.g.r = r; pl.g.a = a; pl.g.A = A;
     pl.g.out = out; pl.g.alpha_out = alpha_out;
+    // algorithmic bytes of one launch: P,Q,h,X in + out (5 n d floats), r, adjacency, a  (SURVEY §8d bytes_B)
+    ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (5.0 * n * d * 4 + d * 4.0 + (double)n * n) + 4.0 * d, st);
     if (pl.lds > 64 * 1024) {
         static int raised = 0;     // benign race: the attribute is idempotent
         if (!raised) {
@@ -606,6 +633,7 @@ static int launch_pool(const float* feat, long ld_b, const float* kq, const uint
     if (n > DIGAT_MAX_NODES || d % 4) return DIGAT_ERR_SHAPE;
     if (B == 0) return DIGAT_OK;
     PoolArgs g{feat, ld_b, kq, mask, addend, out, B, n, d, sqrtf((float)d)};
+    ProfScope prof(DIGAT_KERNEL_POOL, (double)B * ((double)n * d * 4 + 2.0 * d * 4 + n), st);
     hipLaunchKernelGGL(attn_pool_kernel, dim3(B), dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
@@ -673,6 +701,7 @@ static int launch_topic(const float* Xu, long ld_b, const float* kq, const int64
     if (H > TOPIC_MAX_H || d % 4) return DIGAT_ERR_SHAPE;
     if (B == 0) return DIGAT_OK;
     TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d)};
+    ProfScope prof(DIGAT_KERNEL_TOPIC, (double)B * ((double)H * d * 4 + d * 4.0 + H * 8.0 + (double)C1 * d * 4), st);
     hipLaunchKernelGGL(topic_pool_kernel, dim3(B), dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
@@ -767,7 +796,7 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
     g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
     g.nsegs = 3;
-    rc = launch_gemm(g, st);
+    rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
     return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha_out, B, n, d, st);
 }
@@ -901,6 +930,7 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
         const long total4 = (long)B * U * (d / 4);
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
+        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)H * d * 8 + (double)C * d * 4), st);
         hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue,
                            (const float4*)p->topic_node_embedding, (float4*)Xu[0], (long)B, H, C, d / 4);
         DIGAT_CHECK_LAUNCH();
@@ -943,6 +973,43 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
         if (rc) return rc;
     }
     return DIGAT_OK;
+}
+
+int digat_profile_start(int max_launches) {
+    if (max_launches <= 0) return DIGAT_ERR_ARG;
+    if (g_prof.ev) return DIGAT_ERR_ARG;          // already running
+    g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_launches);
+    g_prof.kind = (int*)malloc(sizeof(int) * max_launches);
+    g_prof.work = (double*)malloc(sizeof(double) * max_launches);
+    if (!g_prof.ev || !g_prof.kind || !g_prof.work) return DIGAT_ERR_ARG;
+    for (int i = 0; i < 2 * max_launches; ++i)
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    g_prof.cap = max_launches; g_prof.used = 0; g_prof.enabled = 1;
+    return DIGAT_OK;
+}
+
+int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches_per_kind) {
+    if (!g_prof.ev) return DIGAT_ERR_ARG;
+    g_prof.enabled = 0;
+    for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k) {
+        if (ms_per_kind) ms_per_kind[k] = 0;
+        if (work_per_kind) work_per_kind[k] = 0;
+        if (launches_per_kind) launches_per_kind[k] = 0;
+    }
+    int rc = DIGAT_OK;
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) { rc = DIGAT_ERR_LAUNCH; continue; }
+        const int k = g_prof.kind[i];
+        if (ms_per_kind) ms_per_kind[k] += ms;
+        if (work_per_kind) work_per_kind[k] += g_prof.work[i];
+        if (launches_per_kind) launches_per_kind[k] += 1;
+    }
+    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    free(g_prof.ev); free(g_prof.kind); free(g_prof.work);
+    g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.cap = g_prof.used = 0;
+    return rc;
 }
 
 int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream) {

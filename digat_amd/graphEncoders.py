@@ -151,6 +151,8 @@ class DIGAT(GraphEncoder):
         B, N, d = X.shape
         mask = _lib.as_bytes(news_graph_mask)
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        if B == 0:
+            return out
         L = _lib.lib()
         nbytes = L.digat_news_ctx_workspace_bytes(B, N, d)
         ws = _lib.workspace(nbytes, dev, "ctx")
@@ -172,6 +174,8 @@ class DIGAT(GraphEncoder):
         mask = _lib.as_bytes(user_category_mask)
         idx = user_category_indices.to(torch.int64).contiguous()
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        if B == 0:
+            return out
         L = _lib.lib()
         nbytes = L.digat_user_ctx_workspace_bytes(B, U, H, C1, d)
         ws = _lib.workspace(nbytes, dev, "ctx")
@@ -193,6 +197,8 @@ class DIGAT(GraphEncoder):
         adj = _lib.as_bytes(A)
         out = torch.empty_like(X)
         alpha = torch.empty((B, n, n), dtype=torch.float32, device=dev) if return_alpha else None
+        if B == 0:
+            return (out, alpha) if return_alpha else out
         L = _lib.lib()
         nbytes = L.digat_xattn_workspace_bytes(B, n, d)
         ws = _lib.workspace(nbytes, dev, "xattn")
@@ -232,6 +238,8 @@ class DIGAT(GraphEncoder):
         c0 = None if news_graph_context is None else _lib.f32(news_graph_context)
         out_n = torch.empty((B, d), dtype=torch.float32, device=dev)
         out_u = torch.empty((B, d), dtype=torch.float32, device=dev)
+        if B == 0:                       # empty tensors have no storage to point at
+            return out_n, out_u
         L = _lib.lib()
         nbytes = L.digat_encoder_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")

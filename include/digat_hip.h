@@ -138,6 +138,23 @@ int digat_encoder_fwd(const digat_params* params,
 /* H1: Model.inference's last line (model.py:89): logits[b] = sum_c user_ctx[b,c] * news_ctx[b,c]. */
 int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream);
 
+/* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
+ * Between start and stop every kernel launch of this library is bracketed by two events recorded
+ * on the stream it is launched on.  stop() synchronises and returns, per kernel kind, the summed
+ * duration [ms], the summed algorithmic work (flops for LINEAR/PROJ, bytes for the others) and the
+ * launch count; the three arrays have DIGAT_KERNEL_KINDS entries (any may be NULL). */
+enum {
+    DIGAT_KERNEL_PROJ = 0,    /* [h|P|Q] = X [W|ffn1|ffn2]^T, the Eq. 8 node projections (MFMA) */
+    DIGAT_KERNEL_LINEAR = 1,  /* every other nn.Linear (MFMA)                                    */
+    DIGAT_KERNEL_XATTN = 2,   /* fused Eq. 8 score/softmax/aggregate                             */
+    DIGAT_KERNEL_POOL = 3,    /* ScaledDotProductAttention pooling                               */
+    DIGAT_KERNEL_TOPIC = 4,   /* scatter_softmax + scatter_sum topic pooling                     */
+    DIGAT_KERNEL_GLUE = 5,    /* user-node concat                                                */
+    DIGAT_KERNEL_KINDS = 6
+};
+int digat_profile_start(int max_launches);
+int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches_per_kind);
+
 #ifdef __cplusplus
 }
 #endif
