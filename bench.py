@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — MIND-shaped dev impressions scored per second through the HIP DIGAT path.
+
+A step = one pass of the hot path over one batch of B=1024 (impression, candidate) rows of a synthetic
+MIND-small-shaped dev set: on-device gather of the batch from the HBM-resident corpus tables
+(util.py:65-67 of the reference) + ``Model.inference`` (DIGAT.inference, graph_depth 3, N=10, U=67,
+d=400, fp32) + dot-product logits.  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel of the step, timed live with HIP events over the timed region
+  cpu_baseline  the oracle (unfused reference algorithm, torch-CPU) on a bounded sample, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "mind-small-default": dict(sag_neighbors=3, sag_hops=2, depth=3, category_num=17,
+                               label="MIND-small default: --graph_encoder=DIGAT neighbors=3 hops=2 (N=10, U=67), "
+                                     "d=400, graph_depth=3, fp32 dev inference"),
+    # BASELINE.json configs[2]
+    "mind-small-stress": dict(sag_neighbors=8, sag_hops=2, depth=7, category_num=17,
+                              label="MIND-small stress: neighbors=8 hops=2 (N=65, U=67), d=400, graph_depth=7"),
+    # BASELINE.json configs[3] shape (18 categories)
+    "mind-large-default": dict(sag_neighbors=5, sag_hops=2, depth=3, category_num=18,
+                               label="MIND-large default shape: neighbors=5 hops=2 (N=26, U=68), d=400, graph_depth=3"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per step (reference: batch_size*16 = 1024, main.py:42)")
+    ap.add_argument("--workload", default="mind-small-default", choices=sorted(WORKLOADS))
+    ap.add_argument("--impressions", type=int, default=1024, help="synthetic impressions per rank (~37 rows each)")
+    ap.add_argument("--news", type=int, default=8192, help="synthetic news corpus size per rank")
+    ap.add_argument("--cpu-rows", type=int, default=1536, help="rows of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")          # RCCL on ROCm
+
+    from digat_amd import _lib, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+
+    wl = WORKLOADS[args.workload]
+    spec = synthetic.SynthSpec(news_num=args.news, sag_neighbors=wl["sag_neighbors"], sag_hops=wl["sag_hops"],
+                               category_num=wl["category_num"], impressions=args.impressions, seed=rank)
+    corpus = synthetic.make_corpus(spec)       # each rank owns its shard of the dev rows (weak scaling)
+    N, H, C, d, L = spec.news_graph_size, spec.max_history_num, spec.category_num, spec.embedding_dim, wl["depth"]
+    state = synthetic.make_state_dict(d, C, L, seed=0, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=N, max_history_num=H,
+                                category_num=C, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+
+    dc = util.DeviceCorpus.from_numpy(corpus, dev)
+    util.prepare_news_side(model.graph_encoder, dc, args.batch)     # news cache + c_n0 (setup, untimed)
+    B = args.batch
+    nbatches = max(1, dc.rows // B)
+    mean_cand = corpus.rows / float(spec.impressions)
+
+    scores_buf = torch.empty(B, dtype=torch.float32, device=dev)
+
+    def step(i):
+        s = (i % nbatches) * B
+        e = min(s + B, dc.rows)
+        with torch.no_grad():
+            scores_buf[:e - s] = model.inference(*util.gather_batch(dc, s, e))
+        return e - s
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    _lib.profile_start(64 * (args.steps + 1) * (L + 1))
+    rows_done = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rows_done += step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rows_done], dtype=torch.float64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rows_total = float(r.item())
+    else:
+        rows_total = float(rows_done)
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, summed over the timed region)
+    kinds = {k: v for k, v in prof.items() if v["launches"] > 0}
+    dom = max(kinds, key=lambda k: kinds[k]["ms"])
+
+    def roof(kind):
+        v = kinds[kind]
+        per_launch_ms = v["ms"] / v["launches"]
+        rate = v["work"] / (v["ms"] * 1e-3)
+        if kind in ("proj", "linear"):
+            return {"kernel": kind, "bound": "mfma", "achieved": rate / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": rate / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
+        return {"kernel": kind, "bound": "hbm", "achieved": rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rate / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": per_launch_ms,
+                "launches": v["launches"]}
+
+    kernel_ms = {k: round(v["ms"] / args.steps, 4) for k, v in kinds.items()}
+
+    # ---- CPU baseline + AUC match on a bounded sample (rank 0, N=1 only)
+    cpu_baseline, auc_match = None, None
+    if world == 1 and args.cpu_rows > 0:
+        from oracle import digat_oracle as O      # the checker / baseline, never the product
+        imp_np = corpus.row_impression
+        last_imp = int(imp_np[min(args.cpu_rows, corpus.rows) - 1])
+        n_rows = int(np.searchsorted(imp_np, last_imp, side="left")) or int(np.searchsorted(imp_np, last_imp, side="right"))
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        p = O.as_params(state)
+        emb = torch.from_numpy(corpus.news_embedding)
+        ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
+        sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, d)
+        masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+        with torch.no_grad():
+            c_n0 = O.news_graph_context(p, sa, masks)
+            cpu_scores = []
+            t1 = time.perf_counter()
+            for s in range(0, n_rows, 64):                              # B=64 batches
+                e = min(s + 64, n_rows)
+                imp = torch.from_numpy(corpus.row_impression[s:e])
+                cand = torch.from_numpy(corpus.row_candidate[s:e].astype(np.int64))
+                hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+                ue = emb.index_select(0, hist.flatten()).view(e - s, H, d)
+                cpu_scores.append(O.row_logits(
+                    p, L, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                    torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                    torch.from_numpy(corpus.user_category_indices).index_select(0, imp),
+                    sa.index_select(0, cand), graphs.index_select(0, cand), masks.index_select(0, cand),
+                    c_n0.index_select(0, cand)))
+            cpu_s = time.perf_counter() - t1
+        cpu_scores = torch.cat(cpu_scores).numpy()
+        cpu_baseline = {"value": (n_rows / mean_cand) / cpu_s, "unit": "impressions/s", "cores": cores,
+                        "kind": "port", "rows_per_s": n_rows / cpu_s,
+                        "sample": f"first {n_rows} rows ({last_imp} whole impressions) of the same synthetic dev set, "
+                                  f"unfused reference algorithm (oracle/digat_oracle.py, torch-CPU fp32, B=64 batches), "
+                                  f"{cpu_s:.1f}s"}
+        gpu_scores = util.score_rows(model, dc, 0, n_rows, B).cpu().numpy()
+        from digat_amd import evaluate
+        lab, ri = corpus.row_label[:n_rows], corpus.row_impression[:n_rows]
+        mg = evaluate.scoring(lab, evaluate.impression_ranks(gpu_scores, ri), ri)
+        mc = evaluate.scoring(lab, evaluate.impression_ranks(cpu_scores, ri), ri)
+        auc_match = {"max_abs_metric_diff": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
+                     "max_abs_score_diff": float(np.max(np.abs(gpu_scores - cpu_scores))),
+                     "gpu": [round(v, 6) for v in mg], "cpu": [round(v, 6) for v in mc],
+                     "metrics": ["AUC", "MRR", "nDCG@5", "nDCG@10"], "tolerance": 1e-4}
+
+    value = (rows_total / mean_cand) / elapsed
+    out = {
+        "metric": "MIND dev impressions scored/sec (AUC-matched)",
+        "value": value,
+        "unit": "impressions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl["label"], "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
+                   "mean_candidates_per_impression": round(mean_cand, 3), "parallelism": f"dp{world} (row shards, no data-path collective)"},
+        "rows_per_s": rows_total / elapsed,
+        "roofline": roof(dom),
+        "roofline_xattn": roof("xattn") if "xattn" in kinds else None,
+        "kernel_ms_per_step": kernel_ms,
+        "cpu_baseline": cpu_baseline,
+        "auc_match": auc_match,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""Model assembly: the counterpart of the reference's ``model.py`` (plugin selection + glue).
+
+``config.graph_encoder == 'DIGAT'`` selects the HIP plugin (model.py:18-19); ``forward`` (9 tensors,
+training) and ``inference`` (8 tensors, dev/test) keep the reference's signatures and reshapes
+(model.py:54-90).  The five ablation encoders are not built and raise the same
+``'<name> is not implemented'`` exception the reference raises for unknown names.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib, graphEncoders, newsEncoders
+
+
+class Model(nn.Module):
+    def __init__(self, config, news_encoder: nn.Module = None):
+        super().__init__()
+        if news_encoder is not None:
+            self.news_encoder = news_encoder            # any module exposing .news_embedding_dim
+        elif config.news_encoder == 'CNN':
+            self.news_encoder = newsEncoders.CNN(config)
+        elif config.news_encoder == 'MSA':
+            self.news_encoder = newsEncoders.MSA(config)
+        else:
+            raise Exception(config.news_encoder + ' is not implemented')
+        if config.graph_encoder == 'DIGAT':
+            self.graph_encoder = graphEncoders.DIGAT(config, self.news_encoder.news_embedding_dim)
+        else:
+            raise Exception(config.graph_encoder + ' is not implemented')
+        self.model_name = str(getattr(config, 'news_encoder', 'MSA')) + '-' + config.graph_encoder
+        self.max_title_length = getattr(config, 'max_title_length', 32)
+        self.max_history_num = config.max_history_num
+        self.category_num = config.category_num + 1
+        self.news_embedding_dim = self.news_encoder.news_embedding_dim
+        self.representation_dim = self.news_embedding_dim
+        self.news_graph_size = config.news_graph_size
+        self.user_graph_size = config.max_history_num + config.category_num
+
+    def initialize(self):
+        if hasattr(self.news_encoder, "initialize"):
+            self.news_encoder.initialize()
+        self.graph_encoder.initialize()
+
+    # model.py:54-77
+    def forward(self, user_title_text, user_title_mask, user_graph, user_category_mask, user_category_indices,
+                news_title_text, news_title_mask, news_graph, news_graph_mask):
+        batch_size, news_num = news_graph.size(0), news_graph.size(1)
+        bn = batch_size * news_num
+        news_title_text = news_title_text.view([bn, self.news_graph_size, self.max_title_length])
+        news_title_mask = news_title_mask.view([bn, self.news_graph_size, self.max_title_length])
+        news_graph = news_graph.view([bn, self.news_graph_size, self.news_graph_size])
+        news_graph_mask = news_graph_mask.view([bn, self.news_graph_size])
+
+        def per_candidate(t):
+            return t.unsqueeze(1).expand(-1, news_num, *t.shape[1:]).contiguous().view([bn, *t.shape[1:]])
+
+        user_graph = per_candidate(user_graph)
+        user_category_mask = per_candidate(user_category_mask)
+        user_category_indices = per_candidate(user_category_indices)
+        candidate_news_embedding = self.news_encoder(news_title_text, news_title_mask)
+        user_news_embedding = per_candidate(self.news_encoder(user_title_text, user_title_mask))
+        news_rep, user_rep = self.graph_encoder(candidate_news_embedding, news_graph, news_graph_mask,
+                                                user_news_embedding, user_graph, user_category_mask,
+                                                user_category_indices)
+        news_rep = news_rep.view([batch_size, news_num, self.representation_dim])
+        user_rep = user_rep.view([batch_size, news_num, self.representation_dim])
+        return (user_rep * news_rep).sum(dim=2)
+
+    # model.py:87-90
+    def inference(self, user_news_embedding, user_graph, user_category_mask, user_category_indices,
+                  candidate_news_embedding, news_graph, news_graph_mask, c_n0):
+        news_rep, user_rep = self.graph_encoder.inference(candidate_news_embedding, news_graph, news_graph_mask,
+                                                          user_news_embedding, user_graph, user_category_mask,
+                                                          user_category_indices, c_n0)
+        B, d = news_rep.shape
+        logits = torch.empty(B, dtype=torch.float32, device=news_rep.device)
+        if B:
+            _lib.check(_lib.lib().digat_row_logits(news_rep.data_ptr(), user_rep.data_ptr(), logits.data_ptr(), B, d,
+                                                   _lib.stream_ptr()), "digat_row_logits")
+        return logits
+
+
+class PrecomputedNewsEncoder(nn.Module):
+    """Stand-in producer for synthetic runs: news id -> fixed embedding row (no title text exists).
+    Takes ids shaped [B, n] (the mask argument is ignored) and returns [B, n, d]."""
+
+    def __init__(self, table: torch.Tensor):
+        super().__init__()
+        self.register_buffer("table", table)
+        self.news_embedding_dim = int(table.shape[1])
+
+    def forward(self, news_ids, _mask=None):
+        return self.table[news_ids.long()]

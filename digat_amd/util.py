@@ -1,0 +1,157 @@
+"""Dev/test scoring driver: the counterpart of the reference's ``util.compute_scores`` (util.py:10-85).
+
+Same flow — news-representation cache -> SA gather -> c_n0 precompute -> batched
+``Model.inference`` -> per-impression stable ranking -> AUC/MRR/nDCG — re-laid for one MI355X:
+
+* every corpus table lives in HBM for the whole run (288 GB: MIND-small's user graphs are 328 MB,
+  the SA cache 1 GB); a batch is assembled by on-device ``index_select`` from (impression, candidate)
+  ids instead of 32 DataLoader worker processes building ``[1024,67,67]`` bool arrays item by item
+  (util.py:51-52, MIND_dataset.py:97-102);
+* rows shard across ranks in contiguous impression-aligned blocks (rows are independent, the ranking
+  is per impression), one ``all_gather`` of fp32 scores at the end — no collective on the data path.
+
+The graph encoder is the HIP plugin (``digat_amd.graphEncoders.DIGAT``); nothing here falls back to CPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import evaluate
+
+
+@dataclass
+class DeviceCorpus:
+    """Device-resident corpus tables with the reference's array names (MIND_corpus.py:189-298)."""
+    news_embedding: torch.Tensor         # [news_num, d]   cached_news_representations (util.py:24-33)
+    news_node_ID: torch.Tensor           # [news_num, N]   int64
+    news_graph: torch.Tensor             # [news_num, N, N] bool
+    news_graph_mask: torch.Tensor        # [news_num, N]   bool
+    history: torch.Tensor                # [I, H] int64
+    user_graph: torch.Tensor             # [I, U, U] bool
+    user_category_mask: torch.Tensor     # [I, C+1] bool
+    user_category_indices: torch.Tensor  # [I, H] int64
+    row_impression: torch.Tensor         # [R] int64
+    row_candidate: torch.Tensor          # [R] int64
+    SA_news_representations: Optional[torch.Tensor] = None   # [news_num, N, d] (util.py:36)
+    c_n0: Optional[torch.Tensor] = None                      # [news_num, d]    (util.py:37-44)
+
+    @classmethod
+    def from_numpy(cls, corpus, device) -> "DeviceCorpus":
+        def t(a, dtype=None):
+            x = torch.from_numpy(np.ascontiguousarray(a))
+            return (x.to(dtype) if dtype is not None else x).to(device)
+        return cls(t(corpus.news_embedding), t(corpus.news_node_ID, torch.int64), t(corpus.news_graph),
+                   t(corpus.news_graph_mask), t(corpus.history, torch.int64), t(corpus.user_graph),
+                   t(corpus.user_category_mask), t(corpus.user_category_indices, torch.int64),
+                   t(corpus.row_impression, torch.int64), t(corpus.row_candidate, torch.int64))
+
+    @property
+    def rows(self) -> int:
+        return int(self.row_impression.shape[0])
+
+
+def shard_rows(row_impression: np.ndarray, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, impression-aligned block [start, end) of rows for ``rank``.
+
+    Boundaries are the impression starts nearest to the even split, so every impression is scored by
+    exactly one rank and the blocks concatenate back in row order."""
+    imp = np.asarray(row_impression)
+    R = len(imp)
+    if world_size <= 1:
+        return 0, R
+    starts = np.r_[0, np.flatnonzero(np.diff(imp)) + 1, R]
+
+    def cut(k):
+        if k <= 0:
+            return 0
+        if k >= world_size:
+            return R
+        target = (R * k) // world_size
+        return int(starts[np.searchsorted(starts, target, side="left")])
+    return cut(rank), cut(rank + 1)
+
+
+def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
+    """util.py:34-44: gather the SA neighbourhood embeddings and precompute c_n0 for every news."""
+    news_num, N = dc.news_node_ID.shape
+    d = dc.news_embedding.shape[1]
+    dc.SA_news_representations = dc.news_embedding.index_select(0, dc.news_node_ID.flatten()).view(news_num, N, d)
+    c_n0 = torch.empty((news_num, d), dtype=torch.float32, device=dc.news_embedding.device)
+    with torch.no_grad():
+        for s in range(0, news_num, batch_size):
+            e = min(s + batch_size, news_num)
+            c_n0[s:e] = encoder.compute_news_graph_context(dc.SA_news_representations[s:e], dc.news_graph_mask[s:e])
+    dc.c_n0 = c_n0
+
+
+def gather_batch(dc: DeviceCorpus, start: int, end: int):
+    """The 8 inputs of ``Model.inference`` for rows [start, end) (util.py:57-67), all on device."""
+    imp = dc.row_impression[start:end]
+    cand = dc.row_candidate[start:end]
+    H = dc.history.shape[1]
+    d = dc.news_embedding.shape[1]
+    hist = dc.history.index_select(0, imp)
+    user_rep = dc.news_embedding.index_select(0, hist.flatten()).view(end - start, H, d)
+    return (user_rep, dc.user_graph.index_select(0, imp), dc.user_category_mask.index_select(0, imp),
+            dc.user_category_indices.index_select(0, imp), dc.SA_news_representations.index_select(0, cand),
+            dc.news_graph.index_select(0, cand), dc.news_graph_mask.index_select(0, cand),
+            dc.c_n0.index_select(0, cand))
+
+
+def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int) -> torch.Tensor:
+    """Scores of rows [start, end): the hot loop of util.py:51-69."""
+    scores = torch.empty(end - start, dtype=torch.float32, device=dc.news_embedding.device)
+    with torch.no_grad():
+        for s in range(start, end, batch_size):
+            e = min(s + batch_size, end)
+            scores[s - start:e - start] = model.inference(*gather_batch(dc, s, e))
+    return scores
+
+
+def all_gather_scores(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """Concatenate every rank's block of scores in rank order (blocks are ragged: pad to the max)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    width = max(counts)
+    padded = torch.zeros(width, dtype=local.dtype, device=local.device)
+    padded[:local.numel()] = local
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)])
+
+
+def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np.ndarray] = None,
+                   result_file: Optional[str] = None, rank: int = 0, world_size: int = 1, group=None,
+                   score_fn: Optional[Callable] = None):
+    """Score every row, rank candidates per impression, write the rank file, return
+    ``(scores [R] cpu, (auc, mrr, ndcg5, ndcg10) or None)``.
+
+    ``model`` needs ``.graph_encoder`` (for ``compute_news_graph_context``) and ``.inference``.
+    With ``world_size > 1`` each rank scores its impression-aligned block and the blocks are
+    all-gathered; metrics and the rank file are produced on rank 0 (the others return ``None`` metrics).
+    ``score_fn(model, dc, start, end, batch_size)`` replaces the scorer (tests)."""
+    if hasattr(model, "eval"):
+        model.eval()
+    if dc.c_n0 is None and score_fn is None:
+        prepare_news_side(model.graph_encoder, dc, batch_size)
+    row_imp = dc.row_impression.cpu().numpy()
+    start, end = shard_rows(row_imp, world_size, rank)
+    local = (score_fn or score_rows)(model, dc, start, end, batch_size)
+    if world_size > 1:
+        counts = [shard_rows(row_imp, world_size, r) for r in range(world_size)]
+        scores = all_gather_scores(local, [e - s for s, e in counts], group)
+    else:
+        scores = local
+    scores_np = scores.detach().cpu().numpy()
+    if rank != 0:
+        return scores_np, None
+    ranks = evaluate.impression_ranks(scores_np, row_imp)
+    if result_file is not None:
+        with open(result_file, "w", encoding="utf-8") as f:
+            f.write("\n".join(evaluate.rank_lines(ranks, row_imp)))
+    metrics = evaluate.scoring(labels, ranks, row_imp) if labels is not None else None
+    return scores_np, metrics

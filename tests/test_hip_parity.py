@@ -212,3 +212,38 @@ def test_cpu_tensors_are_refused():
     with pytest.raises(_lib.DigatHipError):
         enc.compute_news_graph_context(torch.from_numpy(batch["news_graph_embeddings"]),
                                        torch.from_numpy(batch["news_graph_mask"]))
+
+
+DEVSETS = {
+    "devset_tiny.npz": dict(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10, category_num=5,
+                            embedding_dim=64, impressions=200, mean_candidates=12.0, max_candidates=40, seed=41),
+    "devset_default.npz": dict(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24, mean_candidates=20.0,
+                               max_candidates=60, seed=43),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEVSETS))
+def test_devset_pipeline_scores_ranks_metrics(name):
+    """H1 + H2: Model.inference driven by compute_scores over the device-resident corpus, against the
+    scores / rank file / metrics the reference produced for the same synthetic dev set."""
+    from digat_amd import evaluate, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    fx = load_golden(name)
+    spec = synthetic.SynthSpec(**DEVSETS[name])
+    corpus = synthetic.make_corpus(spec)
+    L = int(fx["depth"])
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=spec.seed + 1, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    scores, metrics = util.compute_scores(model, dc, 256, labels=corpus.row_label)
+    close(dc.c_n0[:64], fx["c_n0_head"], "c_n0")
+    close(scores, fx["scores"], "scores", rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(metrics, fx["metrics"], rtol=0, atol=1e-4)      # the repo-stated tolerance
+    ranks = evaluate.impression_ranks(scores, corpus.row_impression)
+    ref_ranks = evaluate.impression_ranks(fx["scores"], corpus.row_impression)
+    assert (ranks == ref_ranks).mean() > 0.995                                  # only near-ties may swap

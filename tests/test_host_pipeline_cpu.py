@@ -1,0 +1,103 @@
+"""CPU suite for the host side of the path: ranking/metrics (evaluate.py), impression-aligned row
+sharding and the world_size-2 score gather over gloo (util.py).  The HIP scorer is replaced by a
+deterministic stand-in (``score_fn``) — no GPU compute happens here."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from digat_amd import evaluate, synthetic, util
+
+TINY = synthetic.SynthSpec(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10, category_num=5,
+                           embedding_dim=64, impressions=200, mean_candidates=12.0, max_candidates=40, seed=41)
+
+
+def test_ranks_and_metrics_match_reference_outputs():
+    fx = load_golden("devset_tiny.npz")
+    corpus = synthetic.make_corpus(TINY)
+    ranks = evaluate.impression_ranks(fx["scores"], corpus.row_impression)
+    assert "\n".join(evaluate.rank_lines(ranks, corpus.row_impression)) == str(fx["rank_lines"])
+    got = evaluate.scoring(corpus.row_label, ranks, corpus.row_impression)
+    np.testing.assert_allclose(got, fx["metrics"], rtol=0, atol=1e-9)      # sklearn AUC, MRR, nDCG@5/10
+
+
+def test_ranking_is_stable_on_ties():
+    scores = np.array([0.5, 0.5, 0.9, 0.5, 0.1, 0.1], dtype=np.float32)
+    imp = np.array([0, 0, 0, 0, 1, 1])
+    assert evaluate.impression_ranks(scores, imp).tolist() == [2, 3, 1, 4, 1, 2]
+
+
+def test_metrics_against_sklearn_on_random_impressions():
+    from sklearn.metrics import roc_auc_score
+    rng = np.random.default_rng(0)
+    imp = np.repeat(np.arange(50), rng.integers(2, 30, size=50))
+    labels = np.zeros(len(imp), dtype=np.int8)
+    for i in range(50):
+        sel = np.flatnonzero(imp == i)
+        labels[rng.choice(sel, size=rng.integers(1, len(sel)), replace=False)] = 1
+    scores = rng.standard_normal(len(imp)).astype(np.float32)
+    ranks = evaluate.impression_ranks(scores, imp)
+    auc = evaluate.scoring(labels, ranks, imp)[0]
+    want = np.mean([roc_auc_score(labels[imp == i], 1.0 / ranks[imp == i]) for i in range(50)])
+    assert abs(auc - want) < 1e-12
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_rows_is_an_impression_aligned_partition(world):
+    corpus = synthetic.make_corpus(TINY)
+    imp = corpus.row_impression
+    blocks = [util.shard_rows(imp, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == len(imp)
+    for (s0, e0), (s1, e1) in zip(blocks[:-1], blocks[1:]):
+        assert e0 == s1
+    for s, e in blocks:
+        if 0 < s < len(imp):
+            assert imp[s] != imp[s - 1]          # never splits an impression
+    sizes = [e - s for s, e in blocks]
+    assert max(sizes) - min(sizes) <= 2 * TINY.max_candidates
+
+
+def _fake_scores(model, dc, start, end, batch_size):
+    idx = torch.arange(start, end, dtype=torch.float64)
+    return torch.sin(idx * 12.9898).to(torch.float32) * 3.0
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    corpus = synthetic.make_corpus(TINY)
+    dc = util.DeviceCorpus.from_numpy(corpus, torch.device("cpu"))
+    scores, metrics = util.compute_scores(None, dc, 64, labels=corpus.row_label, rank=rank, world_size=world,
+                                          score_fn=_fake_scores)
+    q.put((rank, scores, metrics))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_equals_single_process():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in procs:
+        r, scores, metrics = q.get(timeout=120)
+        results[r] = (scores, metrics)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = synthetic.make_corpus(TINY)
+    dc = util.DeviceCorpus.from_numpy(corpus, torch.device("cpu"))
+    want_scores, want_metrics = util.compute_scores(None, dc, 64, labels=corpus.row_label, score_fn=_fake_scores)
+    np.testing.assert_array_equal(results[0][0], want_scores)
+    np.testing.assert_array_equal(results[1][0], want_scores)       # all_gather: every rank holds all scores
+    assert results[1][1] is None                                    # metrics on rank 0 only
+    np.testing.assert_allclose(results[0][1], want_metrics, rtol=0, atol=0)
