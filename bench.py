@@ -54,7 +54,8 @@ def parse_args():
     ap.add_argument("--workload", default="mind-small-default", choices=sorted(WORKLOADS))
     ap.add_argument("--impressions", type=int, default=1024, help="synthetic impressions per rank (~37 rows each)")
     ap.add_argument("--news", type=int, default=8192, help="synthetic news corpus size per rank")
-    ap.add_argument("--cpu-rows", type=int, default=1536, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1536, help="max rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -164,8 +165,6 @@ def main():
     if world == 1 and args.cpu_rows > 0:
         from oracle import digat_oracle as O      # the checker / baseline, never the product
         imp_np = corpus.row_impression
-        last_imp = int(imp_np[min(args.cpu_rows, corpus.rows) - 1])
-        n_rows = int(np.searchsorted(imp_np, last_imp, side="left")) or int(np.searchsorted(imp_np, last_imp, side="right"))
         cores = os.cpu_count() or 1
         torch.set_num_threads(cores)
         p = O.as_params(state)
@@ -173,12 +172,21 @@ def main():
         ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
         sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, d)
         masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+        # whole impressions, at most --cpu-rows rows and about --cpu-seconds of CPU work
+        imp_starts = np.r_[0, np.flatnonzero(np.diff(imp_np)) + 1, corpus.rows]
         with torch.no_grad():
             c_n0 = O.news_graph_context(p, sa, masks)
-            cpu_scores = []
+            cpu_scores, n_rows, n_imps = [], 0, 0
             t1 = time.perf_counter()
-            for s in range(0, n_rows, 64):                              # B=64 batches
-                e = min(s + 64, n_rows)
+            while n_imps + 1 < len(imp_starts):
+                s, e = int(imp_starts[n_imps]), int(imp_starts[n_imps + 1])
+                # batch a few impressions together: up to 64 rows per oracle call
+                k = n_imps + 1
+                while k + 1 < len(imp_starts) and int(imp_starts[k + 1]) - s <= 64:
+                    k += 1
+                e = int(imp_starts[k])
+                if e > args.cpu_rows and n_rows > 0:
+                    break
                 imp = torch.from_numpy(corpus.row_impression[s:e])
                 cand = torch.from_numpy(corpus.row_candidate[s:e].astype(np.int64))
                 hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
@@ -189,7 +197,11 @@ def main():
                     torch.from_numpy(corpus.user_category_indices).index_select(0, imp),
                     sa.index_select(0, cand), graphs.index_select(0, cand), masks.index_select(0, cand),
                     c_n0.index_select(0, cand)))
+                n_rows, n_imps = e, k
+                if time.perf_counter() - t1 > args.cpu_seconds:
+                    break
             cpu_s = time.perf_counter() - t1
+        last_imp = n_imps
         cpu_scores = torch.cat(cpu_scores).numpy()
         cpu_baseline = {"value": (n_rows / mean_cand) / cpu_s, "unit": "impressions/s", "cores": cores,
                         "kind": "port", "rows_per_s": n_rows / cpu_s,

@@ -112,6 +112,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int Ntot = g.nseg * g.nsegs;
+    // one weight segment per tile (launch_gemm guarantees tiles never straddle segments), chosen with
+    // scalar arithmetic: a per-lane select of g.w[] makes hipcc fetch the pointer from kernarg memory
+    // with a vector load and a vmcnt(0) in front of every tile load
+    const int seg = n0 / g.nseg;
+    const int nbase = n0 - seg * g.nseg;          // column of this tile inside its segment
+    const float* const wseg = g.w[seg];
     const int ktiles = ((g.K >> 2) + BK4 - 1) / BK4;
 
     float4 ra[A_PER_T], rb[B_PER_T];
@@ -140,13 +146,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                 const int r = g.transW ? i % BN : i / BK4;
                 const int c4 = g.transW ? i / BN : i % BK4;
                 const int gn = n0 + r, k = (kt * BK4 + c4) * 4;
-                if (gn < Ntot && k < g.K) {
-                    const int seg = gn / g.nseg, nn = gn - seg * g.nseg;
-                    const float* wp = seg == 0 ? g.w[0] : (seg == 1 ? g.w[1] : g.w[2]);
+                const int nn = nbase + r;
+                if (nn < g.nseg && gn < Ntot && k < g.K) {
                     if (!g.transW) {
-                        v = *reinterpret_cast<const float4*>(wp + (long)nn * g.K + k);
+                        v = *reinterpret_cast<const float4*>(wseg + (long)nn * g.K + k);
                     } else {
-                        const float* p = wp + (long)k * g.nseg + nn;
+                        const float* p = wseg + (long)k * g.nseg + nn;
                         v = make_float4(p[0], p[g.nseg], p[2 * (long)g.nseg], p[3 * (long)g.nseg]);
                     }
                 }
@@ -221,11 +226,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int gn = n0 + wn * (NT * 16) + nt * 16 + (lane & 15);
-            if (gn >= Ntot) continue;
-            const int seg = gn / g.nseg, nn = gn - seg * g.nseg;
-            const float* bp = seg == 0 ? g.bias[0] : (seg == 1 ? g.bias[1] : g.bias[2]);
-            float* yp = seg == 0 ? g.y[0] : (seg == 1 ? g.y[1] : g.y[2]);
+            const int nn = nbase + wn * (NT * 16) + nt * 16 + (lane & 15);
+            if (nn >= g.nseg) continue;
+            const float* bp = g.bias[seg];
+            float* yp = g.y[seg];
             const float bv = bp ? bp[nn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -250,6 +254,17 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
+    if (g.nsegs > 1 && g.nseg % (g.M >= 2048 ? 80 : 64) != 0) {
+        // a tile must lie inside one weight segment; when the tile width does not divide the segment
+        // (only small test shapes), run the segments one launch each
+        for (int sgm = 0; sgm < g.nsegs; ++sgm) {
+            GemmArgs one = g;
+            one.w[0] = g.w[sgm]; one.bias[0] = g.bias[sgm]; one.y[0] = g.y[sgm]; one.nsegs = 1;
+            const int rc = launch_gemm(one, st, kind);
+            if (rc) return rc;
+        }
+        return DIGAT_OK;
+    }
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.M >= 2048) {
         g.mtiles = (g.M + 127) / 128;
@@ -292,10 +307,11 @@ struct XattnArgs {
     int B, n, d, d4;
     int NT, NP, SN, CC4, nchunks, RB, CW, IG;
     int stage_f4;      // float4 per operand per buffer = RB*CC4*NP
-    int am_off;        // byte offset of the adjacency bytes in LDS
+    int am_off;        // byte offset of the adjacency bytes in LDS (16-B aligned image of the global bytes)
+    int ra_off;        // byte offset of [a (d floats) | r rows (RB*d floats)] in LDS
 };
 constexpr int XA_NPF = 5;    // staged float4 per thread per chunk (upper bound)
-constexpr int XA_IR = 12;    // output rows per thread per aggregation pass
+constexpr int XA_IR = 10;    // output rows per thread per aggregation pass
 
 __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -308,14 +324,28 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
     float4* Ps = reinterpret_cast<float4*>(smem);          // [2][stage_f4]
     float4* Qs = Ps + 2 * g.stage_f4;                      // [2][stage_f4]
     float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the staging buffers
-    uint8_t* Am = smem + g.am_off;                         // [RB][n*n]
+    uint8_t* Am = smem + g.am_off;                         // [RB][n*n] (+ alignment slack)
 
-    // ---- phase 0: clear the staging image (pad positions must hold finite values), adjacency in
+    // ---- phase 0: clear the staging image (pad positions must hold finite values); adjacency bytes,
+    // the score vector a and this workgroup's K3 rows (r) go to LDS with wide loads
     for (int i = tid; i < 4 * g.stage_f4; i += nthreads) Ps[i] = f4_zero();
     {
+        // 16-byte loads from the enclosing aligned window; Am points at the first real byte
         const uint8_t* src = g.A + (long)b0 * n * n;
-        const int nbytes = rows_here * n * n;
-        for (int i = tid; i < nbytes; i += nthreads) Am[i] = src[i];
+        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+        const uint4* src16 = reinterpret_cast<const uint4*>(src - mis);
+        const int nvec = (rows_here * n * n + mis + 15) >> 4;
+        uint4* dst16 = reinterpret_cast<uint4*>(smem + g.am_off);
+        for (int i = tid; i < nvec; i += nthreads) dst16[i] = src16[i];
+        Am += mis;
+    }
+    float4* a_lds = reinterpret_cast<float4*>(smem + g.ra_off);      // [d4]
+    float4* r_lds = a_lds + d4;                                       // [RB][d4]
+    {
+        const float4* a4 = reinterpret_cast<const float4*>(g.a);
+        const float4* r4 = reinterpret_cast<const float4*>(g.r) + (long)b0 * d4;
+        for (int i = tid; i < d4; i += nthreads) a_lds[i] = a4[i];
+        for (int i = tid; i < rows_here * d4; i += nthreads) r_lds[i] = r4[i];
     }
 
     // per-thread staging slots: the decomposition of idx does not depend on the chunk
@@ -323,9 +353,9 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
     const int per_op = rows_here * n * CC4;
     const float* Pblk = g.P + (long)b0 * n * g.d;
     const float* Qblk = g.Q + (long)b0 * n * g.d;
-    const float* rblk = g.r + (long)b0 * g.d;
     int src_off[XA_NPF];
-    int dst_off[XA_NPF];     // < 0: slot unused; bit 30: Q operand; bits 20-29: row of the block (for r)
+    int dst_off[XA_NPF];     // < 0: slot unused; bit 30: Q operand; bits 14-29: float4 index of
+                             // r[rb][c4] in r_lds for chunk 0; bits 0-13: float4 index in the stage image
 #pragma unroll
     for (int u = 0; u < XA_NPF; ++u) {
         const int idx = tid + u * nthreads;
@@ -338,34 +368,28 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
             const int node = rem / CC4, c4 = rem - node * CC4;
             src_off[u] = (rb * n + node) * g.d + c4 * 4;
             const int pos = (node & 3) * NT + (node >> 2);
-            dst_off[u] = ((rb * CC4 + c4) * NP + pos) | (op << 30);
+            dst_off[u] = ((rb * CC4 + c4) * NP + pos) | ((rb * d4 + c4) << 14) | (op << 30);
         }
     }
     float4 pre[XA_NPF];
-    auto prefetch = [&](int ch) {
+    auto prefetch = [&](int ch) {        // loads only: nothing here may wait on memory
 #pragma unroll
         for (int u = 0; u < XA_NPF; ++u) {
             if (dst_off[u] >= 0) {
-                const int op = dst_off[u] >> 30;
-                const float* base = op ? Qblk : Pblk;
-                float4 v = *reinterpret_cast<const float4*>(base + src_off[u] + ch * CC4 * 4);
-                if (!op) {   // K3 + K1 first, as the reference evaluates K3 + K1 + K2
-                    const int rbn = src_off[u] / (n * g.d);
-                    const int col = src_off[u] % g.d;
-                    const float4 rv = *reinterpret_cast<const float4*>(rblk + rbn * g.d + col + ch * CC4 * 4);
-                    v = f4_add(rv, v);
-                }
-                pre[u] = v;
+                const float* base = (dst_off[u] >> 30) ? Qblk : Pblk;
+                pre[u] = *reinterpret_cast<const float4*>(base + src_off[u] + ch * CC4 * 4);
             }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int ch) {
 #pragma unroll
         for (int u = 0; u < XA_NPF; ++u) {
             if (dst_off[u] >= 0) {
                 const int op = dst_off[u] >> 30;
-                float4* dst = (op ? Qs : Ps) + buf * g.stage_f4 + (dst_off[u] & 0x3fffffff);
-                *dst = pre[u];
+                float4 v = pre[u];
+                if (!op) v = f4_add(r_lds[((dst_off[u] >> 14) & 0xffff) + ch * CC4], v);   // K3 + K1 first
+                float4* dst = (op ? Qs : Ps) + buf * g.stage_f4 + (dst_off[u] & 0x3fff);
+                *dst = v;
             }
         }
     };
@@ -384,8 +408,8 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
         for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
 
     prefetch(0);
-    __syncthreads();            // zero fill done before the first commit
-    commit(0);
+    __syncthreads();            // zero fill, a and r in LDS before the first commit
+    commit(0, 0);
     __syncthreads();
     for (int ch = 0; ch < g.nchunks; ++ch) {
         const int buf = ch & 1;
@@ -394,9 +418,9 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
         if (active) {
             const float4* Pb = Ps + buf * g.stage_f4 + rb_t * CC4 * NP;
             const float4* Qb = Qs + buf * g.stage_f4 + rb_t * CC4 * NP;
-            const float4* av = reinterpret_cast<const float4*>(g.a) + ch * CC4;
+            const float4* av = a_lds + ch * CC4;
             for (int c4 = 0; c4 < CC4; ++c4) {
-                const float4 a4 = av[c4];
+                const float4 a4 = av[c4];                     // same address in every lane: LDS broadcast
                 float4 p[4], q[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) p[jj] = Pb[c4 * NP + jj * NT + tj];
@@ -415,7 +439,7 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
                     }
             }
         }
-        if (more) commit(buf ^ 1);   // the other buffer was last read before the previous barrier
+        if (more) commit(buf ^ 1, ch + 1);   // the other buffer was last read before the previous barrier
         __syncthreads();
     }
 
@@ -473,20 +497,27 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
                     float4 o[XA_IR];
 #pragma unroll
                     for (int k = 0; k < XA_IR; ++k) o[k] = f4_zero();
+                    // h rows for the next four neighbours are requested before this step's FMAs
+                    float4 h0 = H4[c4];
+                    float4 h1 = 1 < n ? H4[(long)1 * d4 + c4] : f4_zero();
+                    float4 h2 = 2 < n ? H4[(long)2 * d4 + c4] : f4_zero();
+                    float4 h3 = 3 < n ? H4[(long)3 * d4 + c4] : f4_zero();
                     for (int j = 0; j < n; j += 4) {
-                        const float4 h0 = H4[(long)j * d4 + c4];
-                        const float4 h1 = j + 1 < n ? H4[(long)(j + 1) * d4 + c4] : f4_zero();
-                        const float4 h2 = j + 2 < n ? H4[(long)(j + 2) * d4 + c4] : f4_zero();
-                        const float4 h3 = j + 3 < n ? H4[(long)(j + 3) * d4 + c4] : f4_zero();
+                        const float4 c0 = h0, c1 = h1, c2 = h2, c3 = h3;
+                        const int jn = j + 4;
+                        if (jn < n) h0 = H4[(long)jn * d4 + c4];
+                        h1 = jn + 1 < n ? H4[(long)(jn + 1) * d4 + c4] : f4_zero();
+                        h2 = jn + 2 < n ? H4[(long)(jn + 2) * d4 + c4] : f4_zero();
+                        h3 = jn + 3 < n ? H4[(long)(jn + 3) * d4 + c4] : f4_zero();
 #pragma unroll
                         for (int k = 0; k < XA_IR; ++k) {
                             const int i = ibase + k * g.IG;
                             if (i < n) {
                                 const float4 al = *reinterpret_cast<const float4*>(Srb + i * SN + j);
-                                o[k].x = fmaf(al.w, h3.x, fmaf(al.z, h2.x, fmaf(al.y, h1.x, fmaf(al.x, h0.x, o[k].x))));
-                                o[k].y = fmaf(al.w, h3.y, fmaf(al.z, h2.y, fmaf(al.y, h1.y, fmaf(al.x, h0.y, o[k].y))));
-                                o[k].z = fmaf(al.w, h3.z, fmaf(al.z, h2.z, fmaf(al.y, h1.z, fmaf(al.x, h0.z, o[k].z))));
-                                o[k].w = fmaf(al.w, h3.w, fmaf(al.z, h2.w, fmaf(al.y, h1.w, fmaf(al.x, h0.w, o[k].w))));
+                                o[k].x = fmaf(al.w, c3.x, fmaf(al.z, c2.x, fmaf(al.y, c1.x, fmaf(al.x, c0.x, o[k].x))));
+                                o[k].y = fmaf(al.w, c3.y, fmaf(al.z, c2.y, fmaf(al.y, c1.y, fmaf(al.x, c0.y, o[k].y))));
+                                o[k].z = fmaf(al.w, c3.z, fmaf(al.z, c2.z, fmaf(al.y, c1.z, fmaf(al.x, c0.z, o[k].z))));
+                                o[k].w = fmaf(al.w, c3.w, fmaf(al.z, c2.w, fmaf(al.y, c1.w, fmaf(al.x, c0.w, o[k].w))));
                             }
                         }
                     }
@@ -530,9 +561,11 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
         for (int cc = g.d4; cc >= 1; --cc) {
             if (g.d4 % cc) continue;
             if ((long)2 * rb * n * cc > (long)XA_NPF * threads) continue;
+            if ((long)rb * cc * g.NP >= (1 << 14) || (long)rb * g.d4 >= (1 << 16)) continue;   // packed offsets
             const size_t stage = (size_t)4 * rb * cc * g.NP * 16;
             const size_t sc = (size_t)rb * n * g.SN * 4;
-            const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16);
+            const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
+                               + (size_t)(rb + 1) * d * 4;
             if (tot > lds_budget) continue;
             cc_ok = cc;
             break;
@@ -547,7 +580,8 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     const size_t stage = (size_t)4 * g.stage_f4 * 16;
     const size_t sc = (size_t)g.RB * n * g.SN * 4;
     g.am_off = (int)align_up(stage > sc ? stage : sc, 16);
-    pl->lds = g.am_off + align_up((size_t)g.RB * n * n, 16);
+    g.ra_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
+    pl->lds = g.ra_off + (size_t)(g.RB + 1) * d * 4;
     g.CW = g.d4 < threads ? g.d4 : threads;
     g.IG = threads / g.CW;
     pl->threads = threads;
