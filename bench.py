@@ -45,6 +45,18 @@ WORKLOADS = {
 }
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +177,7 @@ def main():
     if world == 1 and args.cpu_rows > 0:
         from oracle import digat_oracle as O      # the checker / baseline, never the product
         imp_np = corpus.row_impression
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         torch.set_num_threads(cores)
         p = O.as_params(state)
         emb = torch.from_numpy(corpus.news_embedding)

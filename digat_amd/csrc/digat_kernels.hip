@@ -292,28 +292,33 @@ static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float
 }
 
 // =================================================================================================
-// 2. Eq. 8 pairwise kernel (a1/a2 after the projections)
+// 2. Eq. 8 (a1/a2 after the projections): score kernel (VALU) + aggregation kernel (fp32 MFMA)
 // =================================================================================================
-// One thread owns a 4x4 tile of (centre i, neighbour j) pairs and runs the whole sum over the
-// d channels for it in registers (16 accumulators), so no cross-lane reduction is needed for the
-// scores.  P' = r + P (neighbour side, exactly the reference's K3 + K1) and Q (centre side) are
+// Score kernel.  One thread owns a 4x4 tile of (centre i, neighbour j) pairs and runs the whole sum
+// over the d channels for it in registers (16 accumulators), so the scores need no cross-lane
+// reduction.  P' = r + P (neighbour side, exactly the reference's K3 + K1) and Q (centre side) are
 // staged through LDS in channel chunks, double-buffered, in the image [c4][pos(node)] with
-// pos = (node%4)*NT + node/4: the 16 lanes of a ds_read_b128 group then hit consecutive 16-B
-// slots.  Scores go to LDS, one wave per row does the softmax with shuffles, and the aggregation
-// alpha @ h reads h straight from HBM/L2 (each element once per pass) with alpha broadcast from LDS.
-struct XattnArgs {
-    const float* P; const float* Q; const float* Hh; const float* X; const float* r; const float* a;
-    const uint8_t* A; float* out; float* alpha_out;
+// pos = (node%4)*NT + node/4: the 16 lanes of a ds_read_b128 group then hit consecutive 16-B slots.
+// Tiles whose 16 adjacency bytes are all zero are never computed: a per-workgroup list of the
+// non-empty tiles is built from the adjacency image and threads are dealt tiles from that list, so
+// whole waves drop out on sparse graphs (masked scores are replaced by -1e9 whatever their value).
+// Scores go to LDS, one wave per (row, centre) does the masked softmax with shuffles and writes
+// alpha [B,n,n]; [B,n,n,d] is never materialised.
+struct ScoreArgs {
+    const float* P; const float* Q; const float* r; const float* a; const uint8_t* A; float* alpha;
     int B, n, d, d4;
-    int NT, NP, SN, CC4, nchunks, RB, CW, IG;
+    int NT, NP, SN, CC4, nchunks, RB;
     int stage_f4;      // float4 per operand per buffer = RB*CC4*NP
     int am_off;        // byte offset of the adjacency bytes in LDS (16-B aligned image of the global bytes)
     int ra_off;        // byte offset of [a (d floats) | r rows (RB*d floats)] in LDS
+    int tl_off;        // byte offset of the non-empty-tile list (ints) + per-wave counters
+    int skip;          // ablation only (env DIGAT_XATTN_SKIP, 0 in production): 1 no score loop,
+                       // 2 no aggregation launch, 4 no staging loads/commits, 8 no softmax, 16 no empty-tile
+                       // skipping, 32 no score launch
 };
-constexpr int XA_NPF = 5;    // staged float4 per thread per chunk (upper bound)
-constexpr int XA_IR = 10;    // output rows per thread per aggregation pass
+constexpr int XA_NPF = 3;    // staged float4 per thread per chunk (upper bound)
 
-__global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) xattn_score_kernel(const ScoreArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
@@ -325,6 +330,8 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
     float4* Qs = Ps + 2 * g.stage_f4;                      // [2][stage_f4]
     float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the staging buffers
     uint8_t* Am = smem + g.am_off;                         // [RB][n*n] (+ alignment slack)
+    int* tl = reinterpret_cast<int*>(smem + g.tl_off);     // [RB*NT*NT] tile list, then [16] wave counts
+    int* wcnt = tl + g.RB * NT * NT;
 
     // ---- phase 0: clear the staging image (pad positions must hold finite values); adjacency bytes,
     // the score vector a and this workgroup's K3 rows (r) go to LDS with wide loads
@@ -394,28 +401,65 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
         }
     };
 
-    // ---- phase 1: scores
-    const int tiles = NT * NT;
-    const int rb_t = tid / tiles;
-    const int tt = tid - rb_t * tiles;
-    const int ti = tt / NT, tj = tt - ti * NT;
-    const bool active = rb_t < rows_here;
+    prefetch(0);
+    __syncthreads();            // zero fill, adjacency, a and r are in LDS
 
+    // ---- non-empty tiles -> compact list (order = tile id, deterministic)
+    const int tiles = NT * NT;
+    int my_tile = -1;
+    {
+        const int t = tid;
+        bool flag = false;
+        if (t < rows_here * tiles) {
+            const int rb = t / tiles, tt = t - rb * tiles;
+            const int ti = tt / NT, tj = tt - ti * NT;
+            if (g.skip & 16) {
+                flag = true;
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * ti + ii;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * tj + jj;
+                        if (i < n && j < n && Am[(rb * n + i) * n + j] != 0) flag = true;
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(flag);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int c = wcnt[w];
+            if (w < wave) base += c;
+            total += c;
+        }
+        if (flag) tl[base + before] = t;
+        __syncthreads();
+        if (tid < total) my_tile = tl[tid];
+    }
+    const bool active = my_tile >= 0;
+    const int rb_t = active ? my_tile / tiles : 0;
+    const int tt = active ? my_tile - rb_t * tiles : 0;
+    const int ti = tt / NT, tj = tt - ti * NT;
+
+    // ---- phase 1: scores
     float acc[4][4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
 
-    prefetch(0);
-    __syncthreads();            // zero fill, a and r in LDS before the first commit
     commit(0, 0);
     __syncthreads();
     for (int ch = 0; ch < g.nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < g.nchunks;
-        if (more) prefetch(ch + 1);
-        if (active) {
+        if (more && !(g.skip & 4)) prefetch(ch + 1);
+        if (active && !(g.skip & 1)) {
             const float4* Pb = Ps + buf * g.stage_f4 + rb_t * CC4 * NP;
             const float4* Qb = Qs + buf * g.stage_f4 + rb_t * CC4 * NP;
             const float4* av = a_lds + ch * CC4;
@@ -430,21 +474,24 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        float s = acc[ii][jj];
-                        s = fmaf(a4.x, fmaxf(p[jj].x + q[ii].x, 0.f), s);
-                        s = fmaf(a4.y, fmaxf(p[jj].y + q[ii].y, 0.f), s);
-                        s = fmaf(a4.z, fmaxf(p[jj].z + q[ii].z, 0.f), s);
-                        s = fmaf(a4.w, fmaxf(p[jj].w + q[ii].w, 0.f), s);
-                        acc[ii][jj] = s;
+                        float sc = acc[ii][jj];
+                        sc = fmaf(a4.x, fmaxf(p[jj].x + q[ii].x, 0.f), sc);
+                        sc = fmaf(a4.y, fmaxf(p[jj].y + q[ii].y, 0.f), sc);
+                        sc = fmaf(a4.z, fmaxf(p[jj].z + q[ii].z, 0.f), sc);
+                        sc = fmaf(a4.w, fmaxf(p[jj].w + q[ii].w, 0.f), sc);
+                        acc[ii][jj] = sc;
                     }
             }
         }
-        if (more) commit(buf ^ 1, ch + 1);   // the other buffer was last read before the previous barrier
+        if (more && !(g.skip & 4)) commit(buf ^ 1, ch + 1);   // the other buffer was last read before the previous barrier
         __syncthreads();
     }
 
-    // ---- phase 2a: leaky_relu(0.2), adjacency mask (-1e9, not -inf), scores to LDS
-    // (the barrier that ended the chunk loop makes the aliasing of Ss over the staging image safe)
+    // ---- phase 2a: every score starts masked (-1e9, not -inf); the barrier that ended the chunk loop
+    // makes the aliasing of Ss over the staging image safe
+    for (int i = tid; i < rows_here * n * SN; i += nthreads) Ss[i] = -1e9f;
+    __syncthreads();
+    // leaky_relu(0.2) of the computed scores where the adjacency has an edge
     if (active) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
@@ -454,81 +501,114 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = 4 * tj + jj;
                 if (j >= n) continue;
-                float e = acc[ii][jj];
-                e = e > 0.f ? e : 0.2f * e;
-                if (Am[(rb_t * n + i) * n + j] == 0) e = -1e9f;
-                Ss[(rb_t * n + i) * SN + j] = e;
+                if (Am[(rb_t * n + i) * n + j] != 0) {
+                    const float e = acc[ii][jj];
+                    Ss[(rb_t * n + i) * SN + j] = e > 0.f ? e : 0.2f * e;
+                }
             }
         }
     }
     __syncthreads();
 
-    // ---- phase 2b: softmax over the neighbours j, one wave per (row, centre i)
-    for (int rho = wave; rho < rows_here * n; rho += nwaves) {
-        float* srow = Ss + (long)rho * SN;
+    // ---- phase 2b: softmax over the neighbours j, one wave per (row, centre i); a row without any
+    // edge is all -1e9 and comes out uniform, as in the reference
+    for (int rho = wave; rho < ((g.skip & 8) ? 0 : rows_here * n); rho += nwaves) {
+        const float* srow = Ss + (long)rho * SN;
         const float v0 = lane < n ? srow[lane] : -INFINITY;
         const float v1 = lane + 64 < n ? srow[lane + 64] : -INFINITY;
         const float m = wave_max(fmaxf(v0, v1));
         const float e0 = lane < n ? expf(v0 - m) : 0.f;
         const float e1 = lane + 64 < n ? expf(v1 - m) : 0.f;
         const float inv = wave_sum(e0 + e1);
-        const float a0 = e0 / inv, a1 = e1 / inv;
-        if (lane < SN) srow[lane] = a0;                  // pad columns [n, SN) become 0
-        if (lane + 64 < SN) srow[lane + 64] = a1;
-        if (g.alpha_out) {
-            float* arow = g.alpha_out + ((long)b0 * n + rho) * n;
-            if (lane < n) arow[lane] = a0;
-            if (lane + 64 < n) arow[lane + 64] = a1;
+        float* arow = g.alpha + ((long)b0 * n + rho) * n;
+        if (lane < n) arow[lane] = e0 / inv;
+        if (lane + 64 < n) arow[lane + 64] = e1 / inv;
+    }
+}
+
+// Aggregation kernel: out[b] = relu(alpha[b] @ h[b]) + X[b] on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32 is an exact k-ordered fma chain, so this equals a sequential sum over the
+// neighbours j).  One workgroup owns one row b: alpha[b] (n*n floats) is staged in LDS once, each wave
+// owns 64 channels: MFMA column l&15 of channel tile s stands for channel c0 + 4*(l&15) + s, so a lane
+// loads h as one float4 and stores its 4 results as one float4.  h rows are requested AG_PF neighbour
+// steps ahead; alpha blocks (16 centres x 4 neighbours) that are entirely zero — masked pairs — skip
+// their MFMAs.
+struct AggArgs { const float* alpha; const float* Hh; const float* X; float* out; int B, n, d, groups, sa; };
+constexpr int AG_IT = 5;     // 16-row centre tiles per pass (80 centres)
+constexpr int AG_PF = 3;     // neighbour steps of h in flight
+
+__global__ void __launch_bounds__(1024) xattn_agg_kernel(const AggArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* As = reinterpret_cast<float*>(smem);            // [n][sa], sa odd: conflict-free column reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int n = g.n, d = g.d, sa = g.sa;
+    {
+        const float* Ab = g.alpha + (long)b * n * n;
+        for (int e = tid; e < n * n; e += blockDim.x) {
+            const int i = e / n, j = e - i * n;
+            As[i * sa + j] = Ab[e];
         }
     }
     __syncthreads();
+    if (wave >= g.groups) return;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ch = wave * 64 + 4 * lr;
+    const bool ch_ok = ch < d;
+    const float* Hb = g.Hh + (long)b * n * d;
+    const float* Xb = g.X + (long)b * n * d;
+    float* Ob = g.out + (long)b * n * d;
+    const int nit = (n + 15) >> 4;
+    const int nsteps = (n + 3) >> 2;
 
-    // ---- phase 3: out_i = relu(sum_j alpha_ij h_j) + X_i
-    const int cq = tid % g.CW, ig = tid / g.CW;
-    if (ig < g.IG) {
-        for (int rb = 0; rb < rows_here; ++rb) {
-            const long brow = (long)(b0 + rb) * n;
-            const float4* H4 = reinterpret_cast<const float4*>(g.Hh) + brow * d4;
-            const float4* X4 = reinterpret_cast<const float4*>(g.X) + brow * d4;
-            float4* O4 = reinterpret_cast<float4*>(g.out) + brow * d4;
-            const float* Srb = Ss + (long)rb * n * SN;
-            for (int ibase = ig; ibase < n; ibase += g.IG * XA_IR) {
-                for (int c4 = cq; c4 < d4; c4 += g.CW) {
-                    float4 o[XA_IR];
+    auto load_h = [&](int step) -> float4 {
+        const int j = step * 4 + lq;
+        return (j < n && ch_ok) ? *reinterpret_cast<const float4*>(Hb + (long)j * d + ch) : f4_zero();
+    };
+
+    for (int it0 = 0; it0 < nit; it0 += AG_IT) {
+        v4f acc[AG_IT][4];
 #pragma unroll
-                    for (int k = 0; k < XA_IR; ++k) o[k] = f4_zero();
-                    // h rows for the next four neighbours are requested before this step's FMAs
-                    float4 h0 = H4[c4];
-                    float4 h1 = 1 < n ? H4[(long)1 * d4 + c4] : f4_zero();
-                    float4 h2 = 2 < n ? H4[(long)2 * d4 + c4] : f4_zero();
-                    float4 h3 = 3 < n ? H4[(long)3 * d4 + c4] : f4_zero();
-                    for (int j = 0; j < n; j += 4) {
-                        const float4 c0 = h0, c1 = h1, c2 = h2, c3 = h3;
-                        const int jn = j + 4;
-                        if (jn < n) h0 = H4[(long)jn * d4 + c4];
-                        h1 = jn + 1 < n ? H4[(long)(jn + 1) * d4 + c4] : f4_zero();
-                        h2 = jn + 2 < n ? H4[(long)(jn + 2) * d4 + c4] : f4_zero();
-                        h3 = jn + 3 < n ? H4[(long)(jn + 3) * d4 + c4] : f4_zero();
+        for (int it = 0; it < AG_IT; ++it)
 #pragma unroll
-                        for (int k = 0; k < XA_IR; ++k) {
-                            const int i = ibase + k * g.IG;
-                            if (i < n) {
-                                const float4 al = *reinterpret_cast<const float4*>(Srb + i * SN + j);
-                                o[k].x = fmaf(al.w, c3.x, fmaf(al.z, c2.x, fmaf(al.y, c1.x, fmaf(al.x, c0.x, o[k].x))));
-                                o[k].y = fmaf(al.w, c3.y, fmaf(al.z, c2.y, fmaf(al.y, c1.y, fmaf(al.x, c0.y, o[k].y))));
-                                o[k].z = fmaf(al.w, c3.z, fmaf(al.z, c2.z, fmaf(al.y, c1.z, fmaf(al.x, c0.z, o[k].z))));
-                                o[k].w = fmaf(al.w, c3.w, fmaf(al.z, c2.w, fmaf(al.y, c1.w, fmaf(al.x, c0.w, o[k].w))));
-                            }
+            for (int s = 0; s < 4; ++s) acc[it][s] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+        float4 hq[AG_PF];
+#pragma unroll
+        for (int u = 0; u < AG_PF; ++u) hq[u] = load_h(u);
+        for (int step = 0; step < nsteps; step += AG_PF) {
+#pragma unroll
+            for (int u = 0; u < AG_PF; ++u) {
+                const int st = step + u;
+                if (st < nsteps) {
+                    const float4 hc = hq[u];
+                    hq[u] = load_h(st + AG_PF);
+                    const int j = st * 4 + lq;
+#pragma unroll
+                    for (int it = 0; it < AG_IT; ++it) {
+                        const int i = (it0 + it) * 16 + lr;
+                        const float av = (i < n && j < n) ? As[i * sa + j] : 0.f;
+                        if (it0 + it < nit && __any(av != 0.f)) {
+                            acc[it][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hc.x, acc[it][0], 0, 0, 0);
+                            acc[it][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hc.y, acc[it][1], 0, 0, 0);
+                            acc[it][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hc.z, acc[it][2], 0, 0, 0);
+                            acc[it][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hc.w, acc[it][3], 0, 0, 0);
                         }
                     }
+                }
+            }
+        }
+        if (ch_ok) {
 #pragma unroll
-                    for (int k = 0; k < XA_IR; ++k) {
-                        const int i = ibase + k * g.IG;
-                        if (i < n) {
-                            const float4 x = X4[(long)i * d4 + c4];
-                            O4[(long)i * d4 + c4] = make_float4(fmaxf(o[k].x, 0.f) + x.x, fmaxf(o[k].y, 0.f) + x.y,
-                                                                fmaxf(o[k].z, 0.f) + x.z, fmaxf(o[k].w, 0.f) + x.w);
-                        }
+            for (int it = 0; it < AG_IT; ++it) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = (it0 + it) * 16 + 4 * lq + r;
+                    if (i < n) {
+                        const float4 x = *reinterpret_cast<const float4*>(Xb + (long)i * d + ch);
+                        *reinterpret_cast<float4*>(Ob + (long)i * d + ch) =
+                            make_float4(fmaxf(acc[it][0][r], 0.f) + x.x, fmaxf(acc[it][1][r], 0.f) + x.y,
+                                        fmaxf(acc[it][2][r], 0.f) + x.z, fmaxf(acc[it][3][r], 0.f) + x.w);
                     }
                 }
             }
@@ -536,12 +616,12 @@ __global__ void __launch_bounds__(1024) xattn_fwd_kernel(const XattnArgs g) {
     }
 }
 
-struct XattnPlan { XattnArgs g; int threads; size_t lds; int blocks; };
+struct XattnPlan { ScoreArgs g; int threads; size_t lds; int blocks; };
 
 static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     if (B < 0 || n <= 0 || d <= 0) return DIGAT_ERR_ARG;
     if (d % 4 != 0 || n > DIGAT_MAX_NODES) return DIGAT_ERR_SHAPE;
-    XattnArgs& g = pl->g;
+    ScoreArgs& g = pl->g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.n = n; g.d = d; g.d4 = d / 4;
     g.NT = (n + 3) / 4;
@@ -553,26 +633,27 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     else { threads = 256; rbmax = 256 / tiles; }
     if (rbmax > B && B > 0) rbmax = B;
     int bestRB = 0, bestCC = 0;
-    // 64 KiB keeps >= 2 workgroups per CU; graphs too large for that may take up to 150 KiB
-    for (int pass = 0; pass < 2 && !bestRB; ++pass) {
-    const size_t lds_budget = pass == 0 ? 64 * 1024 : 150 * 1024;
-    for (int rb = rbmax; rb >= 1 && !bestRB; --rb) {
-        int cc_ok = 0;
-        for (int cc = g.d4; cc >= 1; --cc) {
-            if (g.d4 % cc) continue;
-            if ((long)2 * rb * n * cc > (long)XA_NPF * threads) continue;
-            if ((long)rb * cc * g.NP >= (1 << 14) || (long)rb * g.d4 >= (1 << 16)) continue;   // packed offsets
-            const size_t stage = (size_t)4 * rb * cc * g.NP * 16;
-            const size_t sc = (size_t)rb * n * g.SN * 4;
-            const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
-                               + (size_t)(rb + 1) * d * 4;
-            if (tot > lds_budget) continue;
-            cc_ok = cc;
-            break;
+    // <= 36 KiB keeps 4 workgroups per CU (1024 rows = one round on 256 CUs); graphs too large for
+    // that may take up to 150 KiB
+    for (int pass = 0; pass < 3 && !bestRB; ++pass) {
+        const size_t lds_budget = pass == 0 ? 36 * 1024 : (pass == 1 ? 64 * 1024 : 150 * 1024);
+        for (int rb = rbmax; rb >= 1 && !bestRB; --rb) {
+            int cc_ok = 0;
+            for (int cc = g.d4; cc >= 1; --cc) {
+                if (g.d4 % cc) continue;
+                if ((long)2 * rb * n * cc > (long)XA_NPF * threads) continue;
+                if ((long)rb * cc * g.NP >= (1 << 14) || (long)rb * g.d4 >= (1 << 16)) continue;   // packed offsets
+                const size_t stage = (size_t)4 * rb * cc * g.NP * 16;
+                const size_t sc = (size_t)rb * n * g.SN * 4;
+                const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
+                                   + (size_t)(rb + 1) * d * 4 + ((size_t)rb * tiles + 16) * 4;
+                if (tot > lds_budget) continue;
+                cc_ok = cc;
+                break;
+            }
+            const int want = g.d4 < 5 ? g.d4 : 5;
+            if (cc_ok >= want || (rb == 1 && cc_ok >= 1)) { bestRB = rb; bestCC = cc_ok; }
         }
-        const int want = g.d4 < 5 ? g.d4 : 5;
-        if (cc_ok >= want || (rb == 1 && cc_ok >= 1)) { bestRB = rb; bestCC = cc_ok; }
-    }
     }
     if (!bestRB) return DIGAT_ERR_SHAPE;
     g.RB = bestRB; g.CC4 = bestCC; g.nchunks = g.d4 / g.CC4;
@@ -581,35 +662,49 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     const size_t sc = (size_t)g.RB * n * g.SN * 4;
     g.am_off = (int)align_up(stage > sc ? stage : sc, 16);
     g.ra_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
-    pl->lds = g.ra_off + (size_t)(g.RB + 1) * d * 4;
-    g.CW = g.d4 < threads ? g.d4 : threads;
-    g.IG = threads / g.CW;
+    g.tl_off = g.ra_off + (g.RB + 1) * d * 4;
+    pl->lds = g.tl_off + ((size_t)g.RB * tiles + 16) * 4;
     pl->threads = threads;
     pl->blocks = (B + g.RB - 1) / g.RB;
     return DIGAT_OK;
 }
 
 static int launch_xattn_pairwise(const float* P, const float* Q, const float* h, const float* X, const float* r,
-                                 const float* a, const uint8_t* A, float* out, float* alpha_out,
+                                 const float* a, const uint8_t* A, float* out, float* alpha,
                                  int B, int n, int d, hipStream_t st) {
     XattnPlan pl;
     const int rc = plan_xattn(B, n, d, &pl);
     if (rc) return rc;
     if (B == 0) return DIGAT_OK;
-    pl.g.P = P; pl.g.Q = Q; pl.g.Hh = h; pl.g.X = X; pl.g.r = r; pl.g.a = a; pl.g.A = A;
-    pl.g.out = out; pl.g.alpha_out = alpha_out;
-    // algorithmic bytes of one launch: P,Q,h,X in + out (5 n d floats), r, adjacency, a  (SURVEY §8d bytes_B)
-    ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (5.0 * n * d * 4 + d * 4.0 + (double)n * n) + 4.0 * d, st);
-    if (pl.lds > 64 * 1024) {
-        static int raised = 0;     // benign race: the attribute is idempotent
-        if (!raised) {
-            if (hipFuncSetAttribute((const void*)xattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
-            raised = 1;
-        }
+    pl.g.P = P; pl.g.Q = Q; pl.g.r = r; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha;
+    {
+        static int skip = -1;
+        if (skip < 0) { const char* e = getenv("DIGAT_XATTN_SKIP"); skip = e ? atoi(e) : 0; }
+        pl.g.skip = skip;
     }
-    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, pl.g);
-    DIGAT_CHECK_LAUNCH();
+    if (!(pl.g.skip & 32)) {
+        // algorithmic bytes of the score launch: P, Q in (2 n d floats), r, adjacency, alpha out, a
+        ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (2.0 * n * d * 4 + d * 4.0 + (double)n * n * 5.0) + 4.0 * d, st);
+        if (pl.lds > 64 * 1024) {
+            static int raised = 0;     // benign race: the attribute is idempotent
+            if (!raised) {
+                if (hipFuncSetAttribute((const void*)xattn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
+                raised = 1;
+            }
+        }
+        hipLaunchKernelGGL(xattn_score_kernel, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, pl.g);
+        DIGAT_CHECK_LAUNCH();
+    }
+    if (!(pl.g.skip & 2)) {
+        AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1};
+        if (ag.groups > 16) return DIGAT_ERR_SHAPE;        // d <= 1024
+        // algorithmic bytes of the aggregation launch: h, X in + out (3 n d floats), alpha in;
+        // flops 2 n^2 d per row run on the MFMA pipe
+        ProfScope prof(DIGAT_KERNEL_AGG, (double)B * (3.0 * n * d * 4 + (double)n * n * 4.0), st);
+        hipLaunchKernelGGL(xattn_agg_kernel, dim3(B), dim3(64 * ag.groups), (size_t)n * ag.sa * 4, st, ag);
+        DIGAT_CHECK_LAUNCH();
+    }
     return DIGAT_OK;
 }
 
@@ -794,15 +889,16 @@ int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b
 
 // ---- a1 / a2 ------------------------------------------------------------------------------------
 size_t digat_xattn_workspace_bytes(int B, int n, int d) {
-    // h, P, Q [B,n,d] + r [B,d]
-    return align_up((size_t)3 * B * n * d * 4, 256) + align_up((size_t)B * d * 4, 256);
+    // h, P, Q [B,n,d] + r [B,d] + alpha [B,n,n]
+    return align_up((size_t)3 * B * n * d * 4, 256) + align_up((size_t)B * d * 4, 256)
+           + align_up((size_t)B * n * n * 4, 256);
 }
 
 int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X, const float* r,
-                             const float* a, const uint8_t* A, float* out, float* alpha_out,
+                             const float* a, const uint8_t* A, float* out, float* alpha,
                              int B, int n, int d, void* stream) {
-    if (!P || !Q || !h || !X || !r || !a || !A || !out) return DIGAT_ERR_ARG;
-    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha_out, B, n, d, (hipStream_t)stream);
+    if (!P || !Q || !h || !X || !r || !a || !A || !out || !alpha) return DIGAT_ERR_ARG;
+    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha, B, n, d, (hipStream_t)stream);
 }
 
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
@@ -821,6 +917,8 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     float* P = h + nd;
     float* Q = P + nd;
     float* r = (float*)((char*)workspace + align_up(3 * nd * 4, 256));
+    float* alpha = alpha_out ? alpha_out
+                             : (float*)((char*)workspace + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
     int rc;
     // r = ctx F3^T + b3   (K3)
     rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
@@ -832,7 +930,7 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     g.nsegs = 3;
     rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
-    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha_out, B, n, d, st);
+    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha, B, n, d, st);
 }
 
 // ---- a3 -----------------------------------------------------------------------------------------

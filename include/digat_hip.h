@@ -61,12 +61,13 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
                     float* out, float* alpha_out, int B, int n, int d,
                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* The Eq. 8 pairwise kernel alone, on already-projected inputs (h = X W^T + bW, P = X F1^T,
- * Q = X F2^T, r = ctx F3^T + b3): score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j -> aggregate.
- * This is the kernel bench.py prices against the HBM roofline. */
+/* The Eq. 8 pairwise part alone, on already-projected inputs (h = X W^T + bW, P = X F1^T,
+ * Q = X F2^T, r = ctx F3^T + b3): score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j (written to
+ * alpha [B,n,n], required) -> out = relu(alpha @ h) + X.  Two launches: the score kernel bench.py
+ * prices against the HBM roofline, and the aggregation on the matrix cores. */
 int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X,
                              const float* r, const float* a, const uint8_t* A,
-                             float* out, float* alpha_out, int B, int n, int d, void* stream);
+                             float* out, float* alpha, int B, int n, int d, void* stream);
 
 /* ---- a3: DIGAT.compute_news_graph_context  (graphEncoders.py:109-114, layers.py:199-206) ------
  * X [B,N,d], mask [B,N] bytes; Kc/Qc/bQc = candidate_attention.{K.weight,Q.weight,Q.bias},
@@ -146,11 +147,12 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 enum {
     DIGAT_KERNEL_PROJ = 0,    /* [h|P|Q] = X [W|ffn1|ffn2]^T, the Eq. 8 node projections (MFMA) */
     DIGAT_KERNEL_LINEAR = 1,  /* every other nn.Linear (MFMA)                                    */
-    DIGAT_KERNEL_XATTN = 2,   /* fused Eq. 8 score/softmax/aggregate                             */
+    DIGAT_KERNEL_XATTN = 2,   /* fused Eq. 8 score + mask + softmax -> alpha                     */
     DIGAT_KERNEL_POOL = 3,    /* ScaledDotProductAttention pooling                               */
     DIGAT_KERNEL_TOPIC = 4,   /* scatter_softmax + scatter_sum topic pooling                     */
     DIGAT_KERNEL_GLUE = 5,    /* user-node concat                                                */
-    DIGAT_KERNEL_KINDS = 6
+    DIGAT_KERNEL_AGG = 6,     /* relu(alpha @ h) + X on the matrix cores                         */
+    DIGAT_KERNEL_KINDS = 7
 };
 int digat_profile_start(int max_launches);
 int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches_per_kind);

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box (development aid, not part of the product or the tests).
+
+  python tools/kbench.py xattn  [B n d]      Eq. 8 pairwise kernel alone (digat_xattn_pairwise_fwd)
+  python tools/kbench.py linear [M N K]      fp32 MFMA linear (digat_linear_f32)
+  python tools/kbench.py encoder             whole DIGAT.inference, per-kernel-kind breakdown
+Timing with torch events on the current stream, median of --iters launches.
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from digat_amd import _lib  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def bench_xattn(B=1024, n=67, d=400, density=None):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    P, Q, h, X = (torch.randn(B, n, d, device=dev, generator=g) for _ in range(4))
+    r = torch.randn(B, d, device=dev, generator=g)
+    a = torch.randn(d, device=dev, generator=g) * 0.1
+    if density == "mind":
+        import numpy as np
+        from digat_amd import synthetic
+        batch = synthetic.make_encoder_batch(B, 10, 50, n - 50, d, seed=0)
+        A = torch.from_numpy(batch["user_graph"]).to(dev).view(torch.uint8)
+        print(f"   MIND-like user graphs: element density {float(batch['user_graph'].mean()):.3f}")
+    elif density is None:
+        A = torch.ones(B, n, n, dtype=torch.uint8, device=dev)
+    else:
+        A = (torch.rand(B, n, n, device=dev, generator=g) < density).to(torch.uint8)
+        A |= torch.eye(n, dtype=torch.uint8, device=dev)[None]
+    out = torch.empty_like(X)
+    alpha = torch.empty(B, n, n, device=dev)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.digat_xattn_pairwise_fwd(P.data_ptr(), Q.data_ptr(), h.data_ptr(), X.data_ptr(), r.data_ptr(),
+                                              a.data_ptr(), A.data_ptr(), out.data_ptr(), alpha.data_ptr(), B, n, d,
+                                              _lib.stream_ptr()), "xattn")
+    med, best = timeit(run)
+    bytes_b = B * (5.0 * n * d * 4 + d * 4 + n * n) + 4 * d
+    lane_ops = 3.0 * B * n * n * d + 2.0 * B * n * n * d / 2
+    print(f"xattn B={B} n={n} d={d} skip={os.environ.get('DIGAT_XATTN_SKIP', '0')}: median {med*1e3:.1f} us  best {best*1e3:.1f} us  "
+          f"{bytes_b/med/1e6:.0f} GB/s algorithmic  ({bytes_b/1e6:.0f} MB)")
+
+
+def bench_linear(M=68608, N=400, K=400):
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    y = torch.empty(M, N, device=dev)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.digat_linear_f32(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, N, K,
+                                      _lib.stream_ptr()), "linear")
+    med, best = timeit(run)
+    fl = 2.0 * M * N * K
+    print(f"linear M={M} N={N} K={K}: median {med*1e3:.1f} us best {best*1e3:.1f} us  {fl/med/1e9:.1f} TFLOP/s")
+    ref = torch.addmm(b, x, w.t())
+    t_ref, _ = timeit(lambda: torch.addmm(b, x, w.t()))
+    print(f"   (rocBLAS addmm for scale: {t_ref*1e3:.1f} us, max|diff| {float((ref - y).abs().max()):.2e})")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "xattn"
+    nums = [int(v) for v in sys.argv[2:]]
+    if what == "xattn":
+        bench_xattn(*nums)
+    elif what == "xattn-mind":
+        bench_xattn(*nums, density="mind")
+    elif what == "linear":
+        bench_linear(*nums)
