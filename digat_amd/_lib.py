@@ -30,7 +30,9 @@ class Params(C.Structure):
                                      "news_graph_W", "news_graph_b", "user_news_K", "user_news_Q",
                                      "user_news_bQ", "featureAffine_W", "featureAffine_b",
                                      "userAtt_K", "userAtt_Q", "userAtt_bQ")]
-                + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)])
+                + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)]
+                + [(k, _f) for k in ("cand_fold_W", "cand_fold_b", "user_news_fold_W", "user_news_fold_b",
+                                     "userAtt_fold_W", "userAtt_fold_b")])
 
 
 class DigatHipError(RuntimeError):
@@ -54,6 +56,8 @@ _SIGNATURES = {
     "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
+    "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -87,7 +87,7 @@ struct GemmArgs {
 // A lane quarter q reads column group 4*kk+q with ds_read_b128 and feeds element s of it to the
 // s-th MFMA k-step (A and B use the same k assignment, so the sum over k is complete); the XOR of
 // the low row bits makes both that read and the staging ds_write_b128 bank-conflict free.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PF>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     constexpr int BK4 = 8;
     constexpr int MT = BM / WAVES_M / 16;
@@ -120,9 +120,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     const float* const wseg = g.w[seg];
     const int ktiles = ((g.K >> 2) + BK4 - 1) / BK4;
 
-    float4 ra[A_PER_T], rb[B_PER_T];
+    // PF register sets: PF = 1 overlaps one tile's loads with the MFMAs of the previous tile (enough when
+    // a tile carries >= 2k MFMA cycles); PF = 2 keeps two tiles in flight for the small-M shapes whose
+    // per-tile MFMA time is far below the load latency
+    float4 ra0[A_PER_T], rb0[B_PER_T], ra1[PF == 2 ? A_PER_T : 1], rb1[PF == 2 ? B_PER_T : 1];
 
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, float4* ra, float4* rb) {
 #pragma unroll
         for (int u = 0; u < A_PER_T; ++u) {
             const int i = tid + u * 256;
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
             rb[u] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const float4* ra, const float4* rb) {
 #pragma unroll
         for (int u = 0; u < A_PER_T; ++u) {
             const int i = tid + u * 256;
@@ -185,12 +188,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const bool more = kt + 1 < ktiles;
-        if (more) load_tiles(kt + 1);          // global loads fly under this tile's MFMAs
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int k4 = kk * 4 + (lane >> 4);
@@ -214,10 +212,43 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                             f4_comp(af[mt], s), f4_comp(bf[nt], s), acc[mt][nt], 0, 0, 0);
         }
+    };
+
+    if (PF == 1) {
+        load_tiles(0, ra0, rb0);
+        store_tiles(ra0, rb0);
         __syncthreads();
-        if (more) {
-            store_tiles();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const bool more = kt + 1 < ktiles;
+            if (more) load_tiles(kt + 1, ra0, rb0);          // global loads fly under this tile's MFMAs
+            compute_tile();
             __syncthreads();
+            if (more) {
+                store_tiles(ra0, rb0);
+                __syncthreads();
+            }
+        }
+    } else {
+        load_tiles(0, ra0, rb0);
+        if (ktiles > 1) load_tiles(1, ra1, rb1);
+        store_tiles(ra0, rb0);
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            // tile kt is in LDS, set 1 holds kt+1 (in flight), set 0 is free
+            if (kt + 2 < ktiles) load_tiles(kt + 2, ra0, rb0);
+            compute_tile();
+            __syncthreads();
+            if (kt + 1 >= ktiles) break;
+            store_tiles(ra1, rb1);
+            __syncthreads();
+            // tile kt+1 is in LDS, set 0 holds kt+2 (in flight), set 1 is free
+            if (kt + 3 < ktiles) load_tiles(kt + 3, ra1, rb1);
+            compute_tile();
+            __syncthreads();
+            if (kt + 2 < ktiles) {
+                store_tiles(ra0, rb0);
+                __syncthreads();
+            }
         }
     }
 
@@ -254,7 +285,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
-    if (g.nsegs > 1 && g.nseg % (g.M >= 2048 ? 80 : 64) != 0) {
+    // tile configuration: 128x80 for the big projections; below 2048 rows 32x64 (most workgroups), or
+    // 64x80 for multi-segment launches whose segments are multiples of 80 columns (d = 400); the small-M
+    // shapes keep two K tiles in flight
+    const int cfg = g.M >= 2048 ? 0 : ((g.nsegs > 1 && g.nseg % 80 == 0) ? 1 : 2);
+    const int bn = cfg == 2 ? 64 : 80;
+    if (g.nsegs > 1 && g.nseg % bn != 0) {
         // a tile must lie inside one weight segment; when the tile width does not divide the segment
         // (only small test shapes), run the segments one launch each
         for (int sgm = 0; sgm < g.nsegs; ++sgm) {
@@ -266,17 +302,13 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         return DIGAT_OK;
     }
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
-    if (g.M >= 2048) {
-        g.mtiles = (g.M + 127) / 128;
-        g.ntiles = (Ntot + 79) / 80;
-        const int total = g.mtiles * g.ntiles;
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
-    } else {
-        g.mtiles = (g.M + 31) / 32;
-        g.ntiles = (Ntot + 63) / 64;
-        const int total = g.mtiles * g.ntiles;
-        hipLaunchKernelGGL((gemm_f32_kernel<32, 64, 1, 4>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
-    }
+    const int bm = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
+    g.mtiles = (g.M + bm - 1) / bm;
+    g.ntiles = (Ntot + bn - 1) / bn;
+    const dim3 grid((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8));
+    if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1, 1>), grid, dim3(256), 0, st, g);
+    else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 80, 4, 1, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<32, 64, 1, 4, 2>), grid, dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
@@ -901,6 +933,26 @@ int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, con
     return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha, B, n, d, (hipStream_t)stream);
 }
 
+// Eq. 8 layer with K3 (r = ctx F3^T + b3) already computed; `r_given` may live anywhere
+static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
+                      const float* W, const float* bW, const float* F1, const float* F2, const float* a,
+                      float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st) {
+    const size_t nd = (size_t)B * n * d;
+    float* h = (float*)workspace;
+    float* P = h + nd;
+    float* Q = P + nd;
+    float* alpha = alpha_out ? alpha_out
+                             : (float*)((char*)workspace + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
+    // [h | P | Q] = X [W | F1 | F2]^T (+ bW on h): one pass over X on the matrix cores
+    GemmArgs g = gemm_plain(X, d, W, bW, h, d, B * n, d, d, 0);
+    g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
+    g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
+    g.nsegs = 3;
+    const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
+    if (rc) return rc;
+    return launch_xattn_pairwise(P, Q, h, X, r_given, a, A, out, alpha, B, n, d, st);
+}
+
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
                     const float* W, const float* bW, const float* F1, const float* F2,
                     const float* F3, const float* b3, const float* a,
@@ -912,25 +964,11 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     if (workspace_bytes < digat_xattn_workspace_bytes(B, n, d)) return DIGAT_ERR_WORKSPACE;
     if (B == 0) return DIGAT_OK;
     hipStream_t st = (hipStream_t)stream;
-    const size_t nd = (size_t)B * n * d;
-    float* h = (float*)workspace;
-    float* P = h + nd;
-    float* Q = P + nd;
-    float* r = (float*)((char*)workspace + align_up(3 * nd * 4, 256));
-    float* alpha = alpha_out ? alpha_out
-                             : (float*)((char*)workspace + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
-    int rc;
+    float* r = (float*)((char*)workspace + align_up((size_t)3 * B * n * d * 4, 256));
     // r = ctx F3^T + b3   (K3)
-    rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
+    const int rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
     if (rc) return rc;
-    // [h | P | Q] = X [W | F1 | F2]^T (+ bW on h): one pass over X on the matrix cores
-    GemmArgs g = gemm_plain(X, d, W, bW, h, d, B * n, d, d, 0);
-    g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
-    g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
-    g.nsegs = 3;
-    rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
-    if (rc) return rc;
-    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha, B, n, d, st);
+    return xattn_core(X, A, r, W, bW, F1, F2, a, out, alpha_out, B, n, d, workspace, st);
 }
 
 // ---- a3 -----------------------------------------------------------------------------------------
@@ -1014,8 +1052,118 @@ int digat_user_ctx_fwd(const float* Xu, const uint8_t* cat_mask, const int64_t* 
     return launch_pool(T2, (long)C1 * d, kq, cat_mask, addend, out, B, C1, d, st);
 }
 
+// ---- folded attention queries (inference): (K x).(Q c + b) = x.(K^T Q c + K^T b) ------------------
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int d) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int y = by + r, x = bx + threadIdx.x;
+        if (y < d && x < d) tile[r][threadIdx.x] = in[(long)y * d + x];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int y = bx + r, x = by + threadIdx.x;
+        if (y < d && x < d) out[(long)y * d + x] = tile[threadIdx.x][r];
+    }
+}
+
+size_t digat_fold_workspace_bytes(int d) { return 2 * align_up((size_t)d * d * 4, 256); }
+
+int digat_fold_attention(const float* K, const float* Q, const float* bQ, float* Wf, float* bf, int d,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!K || !Q || !Wf || !bf || !workspace || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_fold_workspace_bytes(d)) return DIGAT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* Kt = (float*)workspace;
+    float* Qt = (float*)((char*)workspace + align_up((size_t)d * d * 4, 256));
+    const dim3 grid((d + 31) / 32, (d + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, K, Kt, d);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, Q, Qt, d);
+    DIGAT_CHECK_LAUNCH();
+    // Wf[c][i] = sum_o K[o][c] Q[o][i]  = linear(x = K^T [c,o], w = Q^T [i,o])
+    int rc = launch_gemm(gemm_plain(Kt, d, Qt, nullptr, Wf, d, d, d, d, 0), st);
+    if (rc) return rc;
+    // bf[c] = sum_o K[o][c] bQ[o]       = linear(x = bQ [1,o], w = K^T [c,o])
+    if (bQ) return launch_gemm(gemm_plain(bQ, d, Kt, nullptr, bf, d, 1, d, d, 0), st);
+    return hipMemsetAsync(bf, 0, (size_t)d * 4, st) == hipSuccess ? DIGAT_OK : DIGAT_ERR_LAUNCH;
+}
+
 // ---- a5 -----------------------------------------------------------------------------------------
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+// Inference fast path with folded attention queries (digat_fold_attention): per layer the [B,d]
+// linears shrink from 9 launches to 4 — {topic query, user query, next layer's K3 of the user graph}
+// all read the same c_n and go out as ONE three-segment launch.
+static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                              const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
+                              float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
+                              void* xws, void* cws, float* kq_t, float* kq_u, float* r_user, float* r_news,
+                              hipStream_t st) {
+    const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
+    const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
+    float* T = (float*)cws;                       // [B,C1,d] pooled topics
+    float* T2 = (float*)((char*)cws + s2);        // after featureAffine
+    float* glob = (float*)((char*)cws + 2 * s2);  // [B,d]; cws holds >= 2*s2 + 2*[B,d] (user-context layout)
+    int rc;
+    // the user-side queries + (optionally) the next user-graph K3, all from c_n
+    auto from_c_n = [&](int next_layer) -> int {
+        GemmArgs g = gemm_plain(c_n, d, p->user_news_fold_W, p->user_news_fold_b, kq_t, d, B, d, d, 0);
+        g.w[1] = p->userAtt_fold_W; g.bias[1] = p->userAtt_fold_b; g.y[1] = kq_u;
+        g.nsegs = 2;
+        if (next_layer < L) {
+            g.w[2] = p->user[next_layer].F3; g.bias[2] = p->user[next_layer].b3; g.y[2] = r_user;
+            g.nsegs = 3;
+        }
+        return launch_gemm(g, st);
+    };
+    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend) -> int {
+        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, st);
+        if (e) return e;
+        GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
+        g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
+        e = launch_gemm(g, st);
+        if (e) return e;
+        return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, st);
+    };
+    auto news_ctx = [&](const float* Xn_cur) -> int {
+        const long ldx = (long)N * d;
+        float* kq = kq_t;                          // free here: the user side has consumed it
+        int e = launch_gemm(gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0), st);
+        if (e) return e;
+        e = launch_pool(Xn_cur, ldx, kq, Mn, nullptr, glob, B, N, d, st);
+        if (e) return e;
+        GemmArgs g = gemm_plain(Xn_cur, ldx, p->news_graph_W, p->news_graph_b, c_n, d, B, d, 2 * d, 0);
+        g.k0 = d; g.a1 = glob; g.lda1 = d;
+        g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = c_n; g.lde2 = d;
+        return launch_gemm(g, st);
+    };
+
+    rc = from_c_n(0);
+    if (rc) return rc;
+    rc = user_ctx_tail(Xu[0], nullptr);            // c_u (:192)
+    if (rc) return rc;
+    const float* xn_cur = Xn_in;
+    int un = 0, nn = 0;
+    for (int i = 0; i < L; ++i) {
+        const digat_layer_params& ln = p->news[i];
+        const digat_layer_params& lu = p->user[i];
+        rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), st);     // K3 of the news graph
+        if (rc) return rc;
+        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st);
+        if (rc) return rc;
+        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st);
+        if (rc) return rc;
+        xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
+        rc = news_ctx(xn_cur);                     // c_n += ... (:196)
+        if (rc) return rc;
+        rc = from_c_n(i + 1);                      // queries (+ next K3) from the UPDATED c_n
+        if (rc) return rc;
+        rc = user_ctx_tail(Xu[un], c_u);           // c_u += ... (:197)
+        if (rc) return rc;
+    }
+    return DIGAT_OK;
+}
 
 size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
     (void)depth;
@@ -1026,6 +1174,7 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += 2 * align_up((size_t)B * N * d * 4, 256);     // news nodes, ping-pong
     tot += digat_xattn_workspace_bytes(B, nmax, d);
     tot += max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
+    tot += 4 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user, r_news
     return tot;
 }
 
@@ -1054,7 +1203,13 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
     const size_t xws_bytes = digat_xattn_workspace_bytes(B, nmax, d);
     ws += xws_bytes;
     void* cws = ws;
-    const size_t cws_bytes = workspace_bytes - (size_t)(ws - (char*)workspace);
+    const size_t cws_bytes = max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
+    ws += cws_bytes;
+    const size_t sb = align_up((size_t)B * d * 4, 256);
+    float* kq_t = (float*)ws;
+    float* kq_u = (float*)(ws + sb);
+    float* r_user = (float*)(ws + 2 * sb);
+    float* r_news = (float*)(ws + 3 * sb);
 
     int rc;
     // user graph nodes = [history | topic nodes]  (:191)
@@ -1076,6 +1231,9 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
                                 nullptr, out_news, B, N, d, cws, cws_bytes, stream);
         if (rc) return rc;
     }
+    if (p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)
+        return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
+                                  cws, kq_t, kq_u, r_user, r_news, st);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,

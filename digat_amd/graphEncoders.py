@@ -103,7 +103,7 @@ class DIGAT(GraphEncoder):
 
     def _params(self) -> "_lib.Params":
         ptrs = tuple(p.data_ptr() for p in self.parameters())
-        if self._param_block is not None and self._param_block[0] == ptrs:
+        if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
             return self._param_block[1]
         for p in self.parameters():
             if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
@@ -135,8 +135,38 @@ class DIGAT(GraphEncoder):
                 F3 = getattr(self, f"{g}_graph_attention_ffn3")[i]
                 lp.F3, lp.b3 = F3.weight.data_ptr(), F3.bias.data_ptr()
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
-        self._param_block = (ptrs, P)
+        # inference: fold the key projections into the query weights once per weight version
+        P._folds = None
+        if not self.training:
+            P._folds = self._fold_attention()
+            (P.cand_fold_W, P.cand_fold_b, P.user_news_fold_W, P.user_news_fold_b,
+             P.userAtt_fold_W, P.userAtt_fold_b) = (t.data_ptr() for t in P._folds)
+        self._param_block = (ptrs, P, self._fold_key())
         return P
+
+    def _fold_sources(self):
+        ca, ua = self.candidate_attention, self.userAttention
+        return ((ca.K.weight, ca.Q.weight, ca.Q.bias), (self.user_news_K.weight, self.user_news_Q.weight,
+                                                        self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
+
+    def _fold_key(self):
+        return (self.training,) + tuple(t._version for trio in self._fold_sources() for t in trio)
+
+    def _fold_attention(self):
+        """(K x).(Q c + b) = x.(Wf c + bf) with Wf = K^T Q, bf = K^T b, computed by the library itself."""
+        L = _lib.lib()
+        d = self.news_embedding_dim
+        dev = self.topic_node_embedding.device
+        nbytes = L.digat_fold_workspace_bytes(d)
+        ws = _lib.workspace(nbytes, dev, "fold")
+        out = []
+        for K, Q, b in self._fold_sources():
+            Wf = torch.empty((d, d), dtype=torch.float32, device=dev)
+            bf = torch.empty((d,), dtype=torch.float32, device=dev)
+            _lib.check(L.digat_fold_attention(K.data_ptr(), Q.data_ptr(), b.data_ptr(), Wf.data_ptr(), bf.data_ptr(), d,
+                                              ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_fold_attention")
+            out += [Wf, bf]
+        return out
 
     def _eval_only(self, what: str):
         if self.training and self.dropout_rate > 0 and torch.is_grad_enabled():

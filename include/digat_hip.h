@@ -119,7 +119,20 @@ typedef struct digat_params {
     const float *userAtt_K, *userAtt_Q, *userAtt_bQ;        /* userAttention */
     digat_layer_params news[DIGAT_MAX_DEPTH];
     digat_layer_params user[DIGAT_MAX_DEPTH];
+    /* Optional (all three pairs or none; NULL = unfolded path): attention queries with the key
+     * projection folded in by digat_fold_attention — Wf = K^T Q [d,d], bf = K^T bQ [d] — for
+     * candidate_attention, user_news_{K,Q} and userAttention.  Weight-only preprocessing, valid
+     * while the weights do not change (inference). */
+    const float *cand_fold_W, *cand_fold_b;
+    const float *user_news_fold_W, *user_news_fold_b;
+    const float *userAtt_fold_W, *userAtt_fold_b;
 } digat_params;
+
+/* (K x).(Q c + bQ) = x.(Wf c + bf): fold one ScaledDotProductAttention / user_news pair.
+ * K, Q [d,d] nn.Linear weights, bQ [d] or NULL; outputs Wf [d,d] (as an nn.Linear weight), bf [d]. */
+size_t digat_fold_workspace_bytes(int d);
+int digat_fold_attention(const float* K, const float* Q, const float* bQ, float* Wf, float* bf, int d,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* news_graph_embeddings [B,N,d], news_graph [B,N,N], news_graph_mask [B,N],
  * user_news_embedding [B,H,d], user_graph [B,U,U] (U = H + C), user_category_mask [B,C+1],
