@@ -87,7 +87,9 @@ struct GemmArgs {
 // A lane quarter q reads column group 4*kk+q with ds_read_b128 and feeds element s of it to the
 // s-th MFMA k-step (A and B use the same k assignment, so the sum over k is complete); the XOR of
 // the low row bits makes both that read and the staging ds_write_b128 bank-conflict free.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PF>
+// TAG only names the instantiation (0 = nn.Linear, 1 = the Eq. 8 node projections) so that profiles
+// list the projection launches under their own kernel symbol.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PF, int TAG>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     constexpr int BK4 = 8;
     constexpr int MT = BM / WAVES_M / 16;
@@ -306,9 +308,10 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
     g.mtiles = (g.M + bm - 1) / bm;
     g.ntiles = (Ntot + bn - 1) / bn;
     const dim3 grid((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8));
-    if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1, 1>), grid, dim3(256), 0, st, g);
-    else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 80, 4, 1, 2>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<32, 64, 1, 4, 2>), grid, dim3(256), 0, st, g);
+    if (cfg == 0 && kind == DIGAT_KERNEL_PROJ) hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1, 1, 1>), grid, dim3(256), 0, st, g);
+    else if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 80, 4, 1, 1, 0>), grid, dim3(256), 0, st, g);
+    else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 80, 4, 1, 2, 0>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<32, 64, 1, 4, 2, 0>), grid, dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
