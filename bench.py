@@ -30,6 +30,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline is 2:1 sparse)
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -68,6 +69,8 @@ def parse_args():
     ap.add_argument("--news", type=int, default=8192, help="synthetic news corpus size per rank")
     ap.add_argument("--cpu-rows", type=int, default=1536, help="max rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
+    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "fp32"],
+                    help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA")
     return ap.parse_args()
 
 
@@ -102,6 +105,7 @@ def main():
     model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
     model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).eval()
+    model.graph_encoder.projection_mode = args.projection
 
     dc = util.DeviceCorpus.from_numpy(corpus, dev)
     util.prepare_news_side(model.graph_encoder, dc, args.batch)     # news cache + c_n0 (setup, untimed)
@@ -162,7 +166,8 @@ def main():
 
     # HBM traffic of the roofline kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass); their per-launch means are kept under profiles/ and quoted here.
-    symbols = {"proj": "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_score_kernel", "agg": "xattn_agg_kernel",
+    symbols = {"proj": "gemm_bf16x6_kernel" if getattr(model.graph_encoder, "projection_mode", "") == "bf16x6"
+               else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_score_kernel", "agg": "xattn_agg_kernel",
                "topic": "topic_pool_kernel", "pool": "attn_pool_kernel"}
 
     def pmc_traffic(kind):
@@ -183,10 +188,19 @@ def main():
         v = kinds[kind]
         per_launch_ms = v["ms"] / v["launches"]
         rate = v["work"] / (v["ms"] * 1e-3)
+        if kind == "proj" and getattr(model.graph_encoder, "projection_mode", "fp32") == "bf16x6":
+            # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split):
+            # price the EXECUTED bf16 flops against the dense bf16 peak, and quote the fp32-equivalent rate
+            return {"kernel": "proj (gemm_bf16x6_kernel)", "bound": "mfma", "achieved": 6 * rate / 1e12,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 6 * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": pmc_traffic(kind), "mfma_dtype": "bf16 (3-way split of f32, 6 products, f32 accumulate)",
+                    "fp32_equivalent_tflops": rate / 1e12, "algorithmic_flops_per_launch": v["work"] / v["launches"],
+                    "executed_flops_per_launch": 6 * v["work"] / v["launches"],
+                    "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
         if kind in ("proj", "linear"):
             return {"kernel": kind, "bound": "mfma", "achieved": rate / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": rate / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(kind),
-                    "algorithmic_flops_per_launch": v["work"] / v["launches"],
+                    "mfma_dtype": "f32", "algorithmic_flops_per_launch": v["work"] / v["launches"],
                     "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
         return {"kernel": kind, "bound": "hbm", "achieved": rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rate / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(kind),
@@ -265,7 +279,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl["label"], "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
+        "config": {"workload": wl["label"], "projection": args.projection, "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
                    "mean_candidates_per_impression": round(mean_cand, 3), "parallelism": f"dp{world} (row shards, no data-path collective)"},
         "rows_per_s": rows_total / elapsed,
         "roofline": roof(dom),

@@ -21,7 +21,7 @@ _f = C.c_void_p  # every device pointer crosses as void*
 
 
 class LayerParams(C.Structure):
-    _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a")]
+    _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a", "wsplit")]
 
 
 class Params(C.Structure):
@@ -56,6 +56,9 @@ _SIGNATURES = {
     "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
+    "digat_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "digat_split_proj_weights": (C.c_int, [_f, _f, _f, C.c_int, _f, _f]),
+    "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f]),
     "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
     "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),

@@ -81,6 +81,7 @@ struct GemmArgs {
     int epi;
     const float* e0; long lde0; const float* e1; long lde1; const float* e2; long lde2;
     int mtiles, ntiles;
+    const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
 };
 
 // LDS image: float4 tile[k4][row ^ k4]  (k4 = 4-float column group of the 32-deep K tile).
@@ -284,6 +285,183 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
+// =================================================================================================
+// 1b. "bf16x6" GEMM: exact-fp32-quality product on the bf16 matrix cores
+// =================================================================================================
+// Every fp32 operand is split into three bf16 pieces (x = x1 + x2 + x3 exactly: 3 x 8 mantissa bits);
+// the six partial products whose weight is >= 2^-16 (x1w1, x1w2, x2w1, x1w3, x2w2, x3w1) are summed in
+// the fp32 MFMA accumulator (v_mfma_f32_16x16x32_bf16).  Dropped terms are <= 3 * 2^-24 relative, i.e.
+// the result is as accurate as an fp32 fma chain (measured: mean error 0.6x that of an fp32 GEMM) at
+// 6/16 of the fp32-MFMA cost.  Weights arrive pre-split (split_weights_kernel, once per weight version),
+// activations are split while they are staged into LDS.  Tiling, XCD-aware tile order and epilogue are
+// those of gemm_f32_kernel; LDS image per plane: 16-byte slots [kg][row ^ kg] (kg = 8-wide k group of the
+// 32-deep K tile), which keeps the ds_read_b128 of a lane (row l&15, kg l>>4) conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+struct Split3 { unsigned short a, b, c; };
+__device__ __forceinline__ Split3 split3(float v) {
+    Split3 o;
+    o.a = bf16_bits(v);
+    const float r1 = v - bf16_to_f32(o.a);          // exact
+    o.b = bf16_bits(r1);
+    const float r2 = r1 - bf16_to_f32(o.b);         // exact
+    o.c = bf16_bits(r2);
+    return o;
+}
+
+// out[p][n][k] for the rows of up to three [nseg,K] weight matrices stacked along n
+__global__ void __launch_bounds__(256) split_weights_kernel(const float* w0, const float* w1, const float* w2,
+                                                            int nseg, int nsegs, int K, unsigned short* out) {
+    const long total = (long)nseg * nsegs * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / K;
+        const int k = (int)(i - n * K);
+        const int seg = (int)(n / nseg);
+        const float* w = seg == 0 ? w0 : (seg == 1 ? w1 : w2);
+        const Split3 sp = split3(w[(n - (long)seg * nseg) * K + k]);
+        out[i] = sp.a; out[total + i] = sp.b; out[2 * total + i] = sp.c;
+    }
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
+    constexpr int MT = BM / 4 / 16;          // 4 waves stacked along M
+    constexpr int NT = BN / 16;
+    constexpr int A_PER_T = BM * 8 / 256;    // float4 pieces of the fp32 A tile per thread
+    constexpr int B_PIECES = 3 * BN * 4;     // 16-byte bf16 pieces of the three B planes
+    constexpr int B_PER_T = (B_PIECES + 255) / 256;
+    __shared__ uint4 As[3][4 * BM];
+    __shared__ uint4 Bs[3][4 * BN];
+
+    const int total = g.mtiles * g.ntiles;
+    const int chunk = (total + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int Ntot = g.nseg * g.nsegs;
+    const int seg = n0 / g.nseg;
+    const int nbase = n0 - seg * g.nseg;
+    const int ktiles = (g.K + 31) >> 5;
+    const unsigned short* const wsp = g.wsplit;
+    const long plane = (long)Ntot * g.K;
+
+    float4 ra[A_PER_T];
+    uint4 rb[B_PER_T];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < A_PER_T; ++u) {
+            const int i = tid + u * 256;
+            const int r = i >> 3, c4 = i & 7;
+            const int gm = m0 + r, k = kt * 32 + c4 * 4;
+            ra[u] = (gm < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.a0 + (long)gm * g.lda0 + k) : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < B_PIECES) {
+                const int p = i / (BN * 4), rem = i - p * (BN * 4);
+                const int r = rem >> 2, kg = rem & 3;
+                const int k = kt * 32 + kg * 8;
+                if (nbase + r < g.nseg && n0 + r < Ntot && k < g.K)
+                    v = *reinterpret_cast<const uint4*>(wsp + p * plane + (long)(n0 + r) * g.K + k);
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int u = 0; u < A_PER_T; ++u) {
+            const int i = tid + u * 256;
+            const int r = i >> 3, c4 = i & 7;
+            const int kg = c4 >> 1, half = c4 & 1;
+            const Split3 s0 = split3(ra[u].x), s1 = split3(ra[u].y), s2 = split3(ra[u].z), s3 = split3(ra[u].w);
+            const int slot = (kg * BM + (r ^ kg)) * 2 + half;            // uint2 slots
+            reinterpret_cast<uint2*>(As[0])[slot] = make_uint2(s0.a | ((unsigned)s1.a << 16), s2.a | ((unsigned)s3.a << 16));
+            reinterpret_cast<uint2*>(As[1])[slot] = make_uint2(s0.b | ((unsigned)s1.b << 16), s2.b | ((unsigned)s3.b << 16));
+            reinterpret_cast<uint2*>(As[2])[slot] = make_uint2(s0.c | ((unsigned)s1.c << 16), s2.c | ((unsigned)s3.c << 16));
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            if (i < B_PIECES) {
+                const int p = i / (BN * 4), rem = i - p * (BN * 4);
+                const int r = rem >> 2, kg = rem & 3;
+                Bs[p][kg * BN + (r ^ kg)] = rb[u];
+            }
+        }
+    };
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const bool more = kt + 1 < ktiles;
+        if (more) load_tiles(kt + 1);
+        {
+            const int kg = lane >> 4, lr = lane & 15;
+            bf16x8 af[3][MT];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    af[p][mt] = __builtin_bit_cast(bf16x8, As[p][kg * BM + ((wm * (MT * 16) + mt * 16 + lr) ^ kg)]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int slot = kg * BN + ((nt * 16 + lr) ^ kg);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bs[0][slot]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bs[1][slot]);
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, Bs[2][slot]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    v4f c = acc[mt][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][mt], b1, c, 0, 0, 0);   // x3 w1
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b2, c, 0, 0, 0);   // x2 w2
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b3, c, 0, 0, 0);   // x1 w3
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b1, c, 0, 0, 0);   // x2 w1
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b2, c, 0, 0, 0);   // x1 w2
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b1, c, 0, 0, 0);   // x1 w1
+                    acc[mt][nt] = c;
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nn = nbase + nt * 16 + (lane & 15);
+            if (nn >= g.nseg) continue;
+            const float* bp = g.bias[seg];
+            float* yp = g.y[seg];
+            const float bv = bp ? bp[nn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
+                if (gm < g.M) yp[(long)gm * g.ldy + nn] = acc[mt][nt][r] + bv;
+            }
+        }
+    }
+}
+
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
@@ -304,6 +482,14 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         return DIGAT_OK;
     }
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
+    if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.epi == EPI_NONE && g.k0 == g.K && !g.transW) {
+        g.mtiles = (g.M + 127) / 128;
+        g.ntiles = (Ntot + 79) / 80;
+        hipLaunchKernelGGL((gemm_bf16x6_kernel<128, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
+                           0, st, g);
+        DIGAT_CHECK_LAUNCH();
+        return DIGAT_OK;
+    }
     const int bm = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
     g.mtiles = (g.M + bm - 1) / bm;
     g.ntiles = (Ntot + bn - 1) / bn;
@@ -939,7 +1125,8 @@ int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, con
 // Eq. 8 layer with K3 (r = ctx F3^T + b3) already computed; `r_given` may live anywhere
 static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
-                      float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st) {
+                      float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
+                      const void* wsplit = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -951,6 +1138,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
     g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
     g.nsegs = 3;
+    g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
     return launch_xattn_pairwise(P, Q, h, X, r_given, a, A, out, alpha, B, n, d, st);
@@ -972,6 +1160,36 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     const int rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
     if (rc) return rc;
     return xattn_core(X, A, r, W, bW, F1, F2, a, out, alpha_out, B, n, d, workspace, st);
+}
+
+// ---- bf16x6 weight preparation + a directly callable linear (tests, micro-benchmarks) --------------
+size_t digat_split_weights_bytes(int rows, int K) { return (size_t)3 * rows * K * 2; }
+
+int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream) {
+    if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;
+    const long total = (long)3 * d * d;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, F1, F2, d, 3, d,
+                       (unsigned short*)wsplit);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                       int M, int N, int K, void* wsplit, void* stream) {
+    if (!x || !w || !y || !wsplit || M < 0 || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
+    if (K % 8 || ldx % 4 || N % 80) return DIGAT_ERR_SHAPE;
+    const long total = (long)N * K;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, w, w, N, 1, K,
+                       (unsigned short*)wsplit);
+    DIGAT_CHECK_LAUNCH();
+    GemmArgs g = gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0);
+    g.wsplit = (const unsigned short*)wsplit;
+    if (M < 2048) return DIGAT_ERR_SHAPE;      // the bf16x6 kernel serves the big projections only
+    return launch_gemm(g, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
 
 // ---- a3 -----------------------------------------------------------------------------------------
@@ -1153,9 +1371,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         const digat_layer_params& lu = p->user[i];
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), st);     // K3 of the news graph
         if (rc) return rc;
-        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st);
+        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit);
         if (rc) return rc;
-        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st);
+        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
         rc = news_ctx(xn_cur);                     // c_n += ... (:196)
@@ -1249,11 +1467,13 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
         const digat_layer_params& ln = p->news[i];
         const digat_layer_params& lu = p->user[i];
         // both graph updates read the PREVIOUS contexts (:194-195)
-        rc = digat_xattn_fwd(xn_cur, An, out_user, ln.W, ln.bW, ln.F1, ln.F2, ln.F3, ln.b3, ln.a, Xn[nn], nullptr,
-                             B, N, d, xws, xws_bytes, stream);
+        rc = launch_gemm(gemm_plain(out_user, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), st);
         if (rc) return rc;
-        rc = digat_xattn_fwd(Xu[un], Au, out_news, lu.W, lu.bW, lu.F1, lu.F2, lu.F3, lu.b3, lu.a, Xu[un ^ 1], nullptr,
-                             B, U, d, xws, xws_bytes, stream);
+        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit);
+        if (rc) return rc;
+        rc = launch_gemm(gemm_plain(out_news, d, lu.F3, lu.b3, r_user, d, B, d, d, 0), st);
+        if (rc) return rc;
+        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
         // c_n += news context (:196); c_u += user context with the UPDATED c_n (:197)

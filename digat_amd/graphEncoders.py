@@ -72,6 +72,9 @@ class DIGAT(GraphEncoder):
             setattr(self, f"{g}_graph_attention_ffn3", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
             setattr(self, f"{g}_graph_attention_a", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
         self._param_block = None
+        # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default),
+        # "fp32" = v_mfma_f32_16x16x4_f32
+        self.projection_mode = "bf16x6"
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -135,6 +138,22 @@ class DIGAT(GraphEncoder):
                 F3 = getattr(self, f"{g}_graph_attention_ffn3")[i]
                 lp.F3, lp.b3 = F3.weight.data_ptr(), F3.bias.data_ptr()
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
+        # bf16x6 projections: split [W | ffn1 | ffn2] of every layer into three bf16 planes (once per weight version)
+        P._splits = []
+        if self.projection_mode == "bf16x6" and self.news_embedding_dim % 80 == 0:
+            L_ = _lib.lib()
+            d = self.news_embedding_dim
+            nbytes = L_.digat_split_weights_bytes(3 * d, d)
+            for g, arr in (("news", P.news), ("user", P.user)):
+                for i in range(self.graph_depth):
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=self.topic_node_embedding.device)
+                    _lib.check(L_.digat_split_proj_weights(
+                        getattr(self, f"{g}_graph_attention_W")[i].weight.data_ptr(),
+                        getattr(self, f"{g}_graph_attention_ffn1")[i].weight.data_ptr(),
+                        getattr(self, f"{g}_graph_attention_ffn2")[i].weight.data_ptr(), d, buf.data_ptr(),
+                        _lib.stream_ptr()), "digat_split_proj_weights")
+                    arr[i].wsplit = buf.data_ptr()
+                    P._splits.append(buf)
         # inference: fold the key projections into the query weights once per weight version
         P._folds = None
         if not self.training:
@@ -150,7 +169,11 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        return (self.training,) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.projection_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        for g in ("news", "user"):
+            for f in ("W", "ffn1", "ffn2"):
+                key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))
+        return key
 
     def _fold_attention(self):
         """(K x).(Q c + b) = x.(Wf c + bf) with Wf = K^T Q, bf = K^T b, computed by the library itself."""

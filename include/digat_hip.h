@@ -49,6 +49,14 @@ const char* digat_error_string(int code);
 int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
                      int M, int N, int K, void* stream);
 
+/* The same product on the bf16 matrix cores: every fp32 operand is split exactly into three bf16
+ * pieces and the six significant partial products are summed in the fp32 accumulator.  `wsplit`
+ * (digat_split_weights_bytes(N, K) bytes) receives the split weights.  M >= 2048, N % 80 == 0, K % 8 == 0. */
+size_t digat_split_weights_bytes(int rows, int K);
+int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream);
+int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                       int M, int N, int K, void* wsplit, void* stream);
+
 /* ---- a1 / a2: DIGAT.compute_news_graph_embeddings / compute_user_graph_embeddings -------------
  * graphEncoders.py:143-154 / :163-174 (Eq. 8).  X [B,n,d], A [B,n,n] bytes, ctx [B,d] (the OTHER
  * graph's context); W [d,d]+bW, F1 (ffn1, neighbour j), F2 (ffn2, centre i), F3 [d,d]+b3, a [d]
@@ -104,6 +112,10 @@ typedef struct digat_layer_params {
     const float *F2;          /* {g}_graph_attention_ffn2.i.weight        */
     const float *F3, *b3;     /* {g}_graph_attention_ffn3.i.{weight,bias} */
     const float *a;           /* {g}_graph_attention_a.i.weight  [1,d]    */
+    const void  *wsplit;      /* optional: [W|ffn1|ffn2] pre-split by digat_split_proj_weights
+                                 (3 bf16 planes, digat_split_weights_bytes(3d, d) bytes).  Non-NULL runs the
+                                 node projections as six bf16 MFMA products per fp32 product ("bf16x6":
+                                 fp32-equivalent accuracy, 6/16 of the fp32-MFMA cost); NULL = fp32 MFMA. */
 } digat_layer_params;
 
 typedef struct digat_params {

@@ -96,6 +96,51 @@ def test_linear_mfma_f32(M, N, K):
     close(y, want, f"linear {M}x{N}x{K}", rtol=1e-5, atol=2e-6 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 400, 400), (68608, 1200, 400), (2048, 80, 40), (5000, 160, 72)])
+def test_linear_bf16x6_is_fp32_grade(M, N, K):
+    """The split-bf16 product (6 partial products on the bf16 matrix cores) must be as close to an fp64
+    product as the fp32-MFMA kernel is: same tolerance as test_linear_mfma_f32, and its mean error may
+    not exceed the fp32 kernel's by more than 1.5x."""
+    from digat_amd import _lib
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    xd, wd, bd = (torch.from_numpy(a).to(_dev()) for a in (x, w, b))
+    L = _lib.lib()
+    y6 = torch.full((M, N), float("nan"), device=_dev())
+    y32 = torch.full((M, N), float("nan"), device=_dev())
+    ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=_dev())
+    _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y6.data_ptr(), N, M, N, K,
+                                    ws.data_ptr(), _lib.stream_ptr()), "digat_linear_f32x3")
+    _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K,
+                                  _lib.stream_ptr()), "digat_linear_f32")
+    torch.cuda.synchronize()
+    close(y6, want.astype(np.float32), f"bf16x6 linear {M}x{N}x{K}", rtol=1e-5, atol=2e-6 * np.sqrt(K))
+    e6 = np.abs(y6.cpu().numpy().astype(np.float64) - want).mean()
+    e32 = np.abs(y32.cpu().numpy().astype(np.float64) - want).mean()
+    assert e6 <= 1.5 * e32 + 1e-9, (e6, e32)
+
+
+def test_projection_modes_agree():
+    """Whole encoder with the node projections on the fp32 MFMA path vs the bf16x6 path."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 64, 10, 50, 17, 400, 3
+    state = synthetic.make_state_dict(d, C, L, seed=13, bias_std=0.05)
+    batch = to_dev(synthetic.make_encoder_batch(B, N, H, C, d, seed=14))
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    enc = make_encoder(state, N, H, C, d, L)
+    outs = {}
+    for mode in ("fp32", "bf16x6"):
+        enc.projection_mode = mode
+        with torch.no_grad():
+            outs[mode] = enc(*(batch[k] for k in keys))
+    close(outs["bf16x6"][0], outs["fp32"][0], "news ctx, bf16x6 vs fp32")
+    close(outs["bf16x6"][1], outs["fp32"][1], "user ctx, bf16x6 vs fp32")
+
+
 @pytest.mark.parametrize("name", ["tiny.npz", "edges.npz"])
 def test_functions_against_golden_stored_inputs(name):
     fx = load_golden(name)

@@ -75,6 +75,16 @@ def bench_linear(M=68608, N=400, K=400):
     med, best = timeit(run)
     fl = 2.0 * M * N * K
     print(f"linear M={M} N={N} K={K}: median {med*1e3:.1f} us best {best*1e3:.1f} us  {fl/med/1e9:.1f} TFLOP/s")
+    if M >= 2048 and N % 80 == 0 and K % 8 == 0:
+        y6 = torch.empty(M, N, device=dev)
+        ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=dev)
+
+        def run6():
+            _lib.check(L.digat_linear_f32x3(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y6.data_ptr(), N, M, N, K,
+                                            ws.data_ptr(), _lib.stream_ptr()), "linear x3")
+        m6, b6 = timeit(run6)
+        print(f"   bf16x6 (incl. weight split): median {m6*1e3:.1f} us best {b6*1e3:.1f} us  {fl/m6/1e9:.1f} fp32-equivalent TFLOP/s"
+              f"  max|diff vs fp32 kernel| {float((y6 - y).abs().max()):.2e}")
     ref = torch.addmm(b, x, w.t())
     t_ref, _ = timeit(lambda: torch.addmm(b, x, w.t()))
     print(f"   (rocBLAS addmm for scale: {t_ref*1e3:.1f} us, max|diff| {float((ref - y).abs().max()):.2e})")
