@@ -82,6 +82,7 @@ struct GemmArgs {
     const float* e0; long lde0; const float* e1; long lde1; const float* e2; long lde2;
     int mtiles, ntiles;
     const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
+    const float* radd; int radd_seg, rows_per_b;   // segment radd_seg: y += radd[row / rows_per_b][col]  (K3 + K1 of Eq. 8)
 };
 
 // LDS image: float4 tile[k4][row ^ k4]  (k4 = 4-float column group of the 32-deep K tile).
@@ -265,11 +266,13 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
             const float* bp = g.bias[seg];
             float* yp = g.y[seg];
             const float bv = bp ? bp[nn] : 0.f;
+            const float* radd = seg == g.radd_seg ? g.radd : nullptr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
                 if (gm >= g.M) continue;
                 float v = acc[mt][nt][r] + bv;
+                if (radd) v = radd[(long)(gm / g.rows_per_b) * g.nseg + nn] + v;
                 if (g.epi == EPI_RELU_RES) {
                     v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
                 } else if (g.epi == EPI_GATE) {
@@ -453,10 +456,14 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
             const float* bp = g.bias[seg];
             float* yp = g.y[seg];
             const float bv = bp ? bp[nn] : 0.f;
+            const float* radd = seg == g.radd_seg ? g.radd : nullptr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
-                if (gm < g.M) yp[(long)gm * g.ldy + nn] = acc[mt][nt][r] + bv;
+                if (gm >= g.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (radd) v = radd[(long)(gm / g.rows_per_b) * g.nseg + nn] + v;
+                yp[(long)gm * g.ldy + nn] = v;
             }
         }
     }
@@ -476,6 +483,7 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         for (int sgm = 0; sgm < g.nsegs; ++sgm) {
             GemmArgs one = g;
             one.w[0] = g.w[sgm]; one.bias[0] = g.bias[sgm]; one.y[0] = g.y[sgm]; one.nsegs = 1;
+            if (sgm == g.radd_seg) one.radd_seg = 0; else one.radd = nullptr;
             const int rc = launch_gemm(one, st, kind);
             if (rc) return rc;
         }
@@ -517,46 +525,108 @@ static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float
 // =================================================================================================
 // Score kernel.  One thread owns a 4x4 tile of (centre i, neighbour j) pairs and runs the whole sum
 // over the d channels for it in registers (16 accumulators), so the scores need no cross-lane
-// reduction.  P' = r + P (neighbour side, exactly the reference's K3 + K1) and Q (centre side) are
-// staged through LDS in channel chunks, double-buffered, in the image [c4][pos(node)] with
-// pos = (node%4)*NT + node/4: the 16 lanes of a ds_read_b128 group then hit consecutive 16-B slots.
+// reduction.  P' = K3 + K1 (written by the projection GEMM's epilogue, the reference's left-to-right
+// order) and Q stream through LDS in channel chunks by LDS-DMA (global_load_lds_dwordx4: no register
+// round trip), a ring of XA_RING chunk images with two chunks in flight behind hand-counted
+// s_waitcnt vmcnt and ONE raw s_barrier per chunk.  The DMA destination is lane-linear, so the
+// permutation lives in the per-lane SOURCE address: image slot [pos][c4], pos = (node%4)*NT + node/4;
+// with an odd chunk width (5 float4 at d = 400) the 16 lanes of a ds_read_b128 group hit distinct
+// 16-B slots.  Slots of padding positions re-read a real node (finite, never used).
 // Tiles whose 16 adjacency bytes are all zero are never computed: a per-workgroup list of the
 // non-empty tiles is built from the adjacency image and threads are dealt tiles from that list, so
 // whole waves drop out on sparse graphs (masked scores are replaced by -1e9 whatever their value).
 // Scores go to LDS, one wave per (row, centre) does the masked softmax with shuffles and writes
 // alpha [B,n,n]; [B,n,n,d] is never materialised.
 struct ScoreArgs {
-    const float* P; const float* Q; const float* r; const float* a; const uint8_t* A; float* alpha;
+    const float* P;    // P' = r + P  (K3 + K1)
+    const float* Q; const float* a; const uint8_t* A; float* alpha;
     int B, n, d, d4;
-    int NT, NP, SN, CC4, nchunks, RB;
-    int stage_f4;      // float4 per operand per buffer = RB*CC4*NP
+    int NT, SN, CC4, nchunks, RB;
+    int img_slots;     // float4 slots of one operand image of one chunk = RB * 4*NT * CC4
+    int ring_slots;    // slots of one ring buffer: both operands, padded to a multiple of 64
+    int ninstr;        // DMA wave-instructions per chunk = ring_slots / 64
     int am_off;        // byte offset of the adjacency bytes in LDS (16-B aligned image of the global bytes)
-    int ra_off;        // byte offset of [a (d floats) | r rows (RB*d floats)] in LDS
+    int a_off;         // byte offset of a (d floats) in LDS
     int tl_off;        // byte offset of the non-empty-tile list (ints) + per-wave counters
     int skip;          // ablation only (env DIGAT_XATTN_SKIP, 0 in production): 1 no score loop,
-                       // 2 no aggregation launch, 4 no staging loads/commits, 8 no softmax, 16 no empty-tile
-                       // skipping, 32 no score launch
+                       // 2 no aggregation launch, 8 no softmax, 16 no empty-tile skipping, 32 no score launch
 };
-constexpr int XA_NPF = 3;    // staged float4 per thread per chunk (upper bound)
+constexpr int XA_RING = 3;   // chunk images in the LDS ring
+constexpr int XA_KMAX = 4;   // DMA wave-instructions one wave issues per chunk (upper bound)
+
+// one 16-byte-per-lane global -> LDS copy; LDS address = lds_byte_addr (wave-uniform) + 16*lane.
+// Invisible to hipcc's waitcnt bookkeeping: completion is counted by hand (wait_vmcnt below).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
 
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) xattn_score_kernel(const ScoreArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
     const int b0 = blockIdx.x * g.RB;
     const int rows_here = min(g.RB, g.B - b0);
-    const int n = g.n, NT = g.NT, NP = g.NP, CC4 = g.CC4, SN = g.SN, d4 = g.d4;
+    const int n = g.n, NT = g.NT, CC4 = g.CC4, SN = g.SN, d4 = g.d4;
 
-    float4* Ps = reinterpret_cast<float4*>(smem);          // [2][stage_f4]
-    float4* Qs = Ps + 2 * g.stage_f4;                      // [2][stage_f4]
-    float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the staging buffers
+    float4* ring = reinterpret_cast<float4*>(smem);        // [XA_RING][ring_slots]: P' image, then Q image
+    float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the ring after the chunk loop
     uint8_t* Am = smem + g.am_off;                         // [RB][n*n] (+ alignment slack)
+    float4* a_lds = reinterpret_cast<float4*>(smem + g.a_off);
     int* tl = reinterpret_cast<int*>(smem + g.tl_off);     // [RB*NT*NT] tile list, then [16] wave counts
     int* wcnt = tl + g.RB * NT * NT;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    // ---- phase 0: clear the staging image (pad positions must hold finite values); adjacency bytes,
-    // the score vector a and this workgroup's K3 rows (r) go to LDS with wide loads
-    for (int i = tid; i < 4 * g.stage_f4; i += nthreads) Ps[i] = f4_zero();
+    // ---- this wave's DMA pieces: instruction q = wave + nwaves*k covers image slots [64q, 64q+64)
+    const float* Pblk = g.P + (long)b0 * n * g.d;
+    const float* Qblk = g.Q + (long)b0 * n * g.d;
+    int src_off[XA_KMAX];        // float offset of this lane's source at chunk 0; bit 31: Q operand
+    int kw = 0;                  // wave-uniform: instructions this wave issues per chunk
+#pragma unroll
+    for (int k = 0; k < XA_KMAX; ++k) {
+        const int q = wave + nwaves * k;
+        src_off[k] = 0;
+        if (q < g.ninstr) {
+            kw = k + 1;
+            int slot = q * 64 + lane;
+            if (slot >= 2 * g.img_slots) slot = 2 * g.img_slots - 1;           // padding lanes re-read the last slot
+            const int op = slot >= g.img_slots;
+            const int e = slot - op * g.img_slots;
+            const int per_row = 4 * NT * CC4;
+            int rb = e / per_row;
+            const int rem = e - rb * per_row;
+            const int pos = rem / CC4, c4 = rem - pos * CC4;
+            int node = (pos % NT) * 4 + pos / NT;
+            if (node >= n) node = n - 1;                                       // padding positions: any real node
+            if (rb >= rows_here) rb = rows_here - 1;
+            src_off[k] = ((rb * n + node) * g.d + c4 * 4) | (op << 31);
+        }
+    }
+    auto issue = [&](int ch, int buf) {
+#pragma unroll
+        for (int k = 0; k < XA_KMAX; ++k) {
+            if (k < kw) {
+                const int q = wave + nwaves * k;
+                const float* base = (src_off[k] < 0) ? Qblk : Pblk;
+                lds_dma16(base + (src_off[k] & 0x7fffffff) + ch * CC4 * 4,
+                          ring_lds + (unsigned)((buf * g.ring_slots + q * 64) * 16));
+            }
+        }
+    };
+    issue(0, 0);
+    if (g.nchunks > 1) issue(1, 1);
+
+    // ---- phase 0: adjacency bytes and the score vector a go to LDS with wide loads
     {
         // 16-byte loads from the enclosing aligned window; Am points at the first real byte
         const uint8_t* src = g.A + (long)b0 * n * n;
@@ -566,64 +636,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
         uint4* dst16 = reinterpret_cast<uint4*>(smem + g.am_off);
         for (int i = tid; i < nvec; i += nthreads) dst16[i] = src16[i];
         Am += mis;
-    }
-    float4* a_lds = reinterpret_cast<float4*>(smem + g.ra_off);      // [d4]
-    float4* r_lds = a_lds + d4;                                       // [RB][d4]
-    {
         const float4* a4 = reinterpret_cast<const float4*>(g.a);
-        const float4* r4 = reinterpret_cast<const float4*>(g.r) + (long)b0 * d4;
         for (int i = tid; i < d4; i += nthreads) a_lds[i] = a4[i];
-        for (int i = tid; i < rows_here * d4; i += nthreads) r_lds[i] = r4[i];
     }
-
-    // per-thread staging slots: the decomposition of idx does not depend on the chunk
-    // (32-bit offsets relative to this workgroup's first row keep the register count down)
-    const int per_op = rows_here * n * CC4;
-    const float* Pblk = g.P + (long)b0 * n * g.d;
-    const float* Qblk = g.Q + (long)b0 * n * g.d;
-    int src_off[XA_NPF];
-    int dst_off[XA_NPF];     // < 0: slot unused; bit 30: Q operand; bits 14-29: float4 index of
-                             // r[rb][c4] in r_lds for chunk 0; bits 0-13: float4 index in the stage image
-#pragma unroll
-    for (int u = 0; u < XA_NPF; ++u) {
-        const int idx = tid + u * nthreads;
-        dst_off[u] = -1; src_off[u] = 0;
-        if (idx < 2 * per_op) {
-            const int op = idx >= per_op;
-            const int e = idx - op * per_op;
-            const int rb = e / (n * CC4);
-            const int rem = e - rb * (n * CC4);
-            const int node = rem / CC4, c4 = rem - node * CC4;
-            src_off[u] = (rb * n + node) * g.d + c4 * 4;
-            const int pos = (node & 3) * NT + (node >> 2);
-            dst_off[u] = ((rb * CC4 + c4) * NP + pos) | ((rb * d4 + c4) << 14) | (op << 30);
-        }
-    }
-    float4 pre[XA_NPF];
-    auto prefetch = [&](int ch) {        // loads only: nothing here may wait on memory
-#pragma unroll
-        for (int u = 0; u < XA_NPF; ++u) {
-            if (dst_off[u] >= 0) {
-                const float* base = (dst_off[u] >> 30) ? Qblk : Pblk;
-                pre[u] = *reinterpret_cast<const float4*>(base + src_off[u] + ch * CC4 * 4);
-            }
-        }
-    };
-    auto commit = [&](int buf, int ch) {
-#pragma unroll
-        for (int u = 0; u < XA_NPF; ++u) {
-            if (dst_off[u] >= 0) {
-                const int op = dst_off[u] >> 30;
-                float4 v = pre[u];
-                if (!op) v = f4_add(r_lds[((dst_off[u] >> 14) & 0xffff) + ch * CC4], v);   // K3 + K1 first
-                float4* dst = (op ? Qs : Ps) + buf * g.stage_f4 + (dst_off[u] & 0x3fff);
-                *dst = v;
-            }
-        }
-    };
-
-    prefetch(0);
-    __syncthreads();            // zero fill, adjacency, a and r are in LDS
+    __syncthreads();            // (also drains the first DMA pieces; the loop's counted waits take over below)
 
     // ---- non-empty tiles -> compact list (order = tile id, deterministic)
     const int tiles = NT * NT;
@@ -674,23 +690,23 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
 
-    commit(0, 0);
-    __syncthreads();
     for (int ch = 0; ch < g.nchunks; ++ch) {
-        const int buf = ch & 1;
-        const bool more = ch + 1 < g.nchunks;
-        if (more && !(g.skip & 4)) prefetch(ch + 1);
+        // chunk ch has landed once at most the newer chunk's pieces of THIS wave are outstanding ...
+        wait_vmcnt(ch + 1 < g.nchunks ? kw : 0);
+        // ... and every wave has said so: the barrier publishes chunk ch and retires chunk ch-1's readers
+        __builtin_amdgcn_s_barrier();
+        if (ch + 2 < g.nchunks) issue(ch + 2, (ch + 2) % XA_RING);      // into the image read in iteration ch-1
         if (active && !(g.skip & 1)) {
-            const float4* Pb = Ps + buf * g.stage_f4 + rb_t * CC4 * NP;
-            const float4* Qb = Qs + buf * g.stage_f4 + rb_t * CC4 * NP;
+            const float4* Pb = ring + (ch % XA_RING) * g.ring_slots + rb_t * 4 * NT * CC4;
+            const float4* Qb = Pb + g.img_slots;
             const float4* av = a_lds + ch * CC4;
             for (int c4 = 0; c4 < CC4; ++c4) {
                 const float4 a4 = av[c4];                     // same address in every lane: LDS broadcast
                 float4 p[4], q[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) p[jj] = Pb[c4 * NP + jj * NT + tj];
+                for (int jj = 0; jj < 4; ++jj) p[jj] = Pb[(jj * NT + tj) * CC4 + c4];
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) q[ii] = Qb[c4 * NP + ii * NT + ti];
+                for (int ii = 0; ii < 4; ++ii) q[ii] = Qb[(ii * NT + ti) * CC4 + c4];
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -704,12 +720,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                     }
             }
         }
-        if (more && !(g.skip & 4)) commit(buf ^ 1, ch + 1);   // the other buffer was last read before the previous barrier
-        __syncthreads();
     }
+    __syncthreads();            // every wave is done with the ring: Ss may alias it
 
-    // ---- phase 2a: every score starts masked (-1e9, not -inf); the barrier that ended the chunk loop
-    // makes the aliasing of Ss over the staging image safe
+    // ---- phase 2a: every score starts masked (-1e9, not -inf)
     for (int i = tid; i < rows_here * n * SN; i += nthreads) Ss[i] = -1e9f;
     __syncthreads();
     // leaky_relu(0.2) of the computed scores where the adjacency has an edge
@@ -846,66 +860,74 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     memset(&g, 0, sizeof(g));
     g.B = B; g.n = n; g.d = d; g.d4 = d / 4;
     g.NT = (n + 3) / 4;
-    g.NP = 4 * g.NT + 1;
     g.SN = (n + 3) / 4 * 4;
     const int tiles = g.NT * g.NT;
     int threads, rbmax;
     if (tiles >= 128) { threads = (tiles + 63) / 64 * 64; rbmax = 1; }
     else { threads = 256; rbmax = 256 / tiles; }
     if (rbmax > B && B > 0) rbmax = B;
+    const int nwaves = threads / 64;
     int bestRB = 0, bestCC = 0;
-    // <= 36 KiB keeps 4 workgroups per CU (1024 rows = one round on 256 CUs); graphs too large for
-    // that may take up to 150 KiB
+    // <= 40 KiB keeps 4 workgroups per CU (1024 rows = one round on 256 CUs); graphs too large for
+    // that may take up to 150 KiB.  The DMA ring must sit in the first 64 KiB of LDS (M0 addressing).
     for (int pass = 0; pass < 3 && !bestRB; ++pass) {
-        const size_t lds_budget = pass == 0 ? 36 * 1024 : (pass == 1 ? 64 * 1024 : 150 * 1024);
+        const size_t lds_budget = pass == 0 ? 40 * 1024 : (pass == 1 ? 64 * 1024 : 150 * 1024);
         for (int rb = rbmax; rb >= 1 && !bestRB; --rb) {
             int cc_ok = 0;
-            for (int cc = g.d4; cc >= 1; --cc) {
-                if (g.d4 % cc) continue;
-                if ((long)2 * rb * n * cc > (long)XA_NPF * threads) continue;
-                if ((long)rb * cc * g.NP >= (1 << 14) || (long)rb * g.d4 >= (1 << 16)) continue;   // packed offsets
-                const size_t stage = (size_t)4 * rb * cc * g.NP * 16;
-                const size_t sc = (size_t)rb * n * g.SN * 4;
-                const size_t tot = align_up(stage > sc ? stage : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
-                                   + (size_t)(rb + 1) * d * 4 + ((size_t)rb * tiles + 16) * 4;
-                if (tot > lds_budget) continue;
-                cc_ok = cc;
-                break;
+            // odd chunk widths first (conflict-free LDS reads), widest first
+            for (int odd = 1; odd >= 0 && !cc_ok; --odd) {
+                for (int cc = g.d4; cc >= 1; --cc) {
+                    if (g.d4 % cc || (cc & 1) != odd) continue;
+                    const long img = (long)rb * 4 * g.NT * cc;
+                    const long ring_slots = (2 * img + 63) / 64 * 64;
+                    if (ring_slots / 64 > (long)XA_KMAX * nwaves) continue;
+                    if ((size_t)XA_RING * ring_slots * 16 > 60 * 1024) continue;
+                    const size_t sc = (size_t)rb * n * g.SN * 4;
+                    const size_t ringb = (size_t)XA_RING * ring_slots * 16;
+                    const size_t tot = align_up(ringb > sc ? ringb : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
+                                       + (size_t)d * 4 + ((size_t)rb * tiles + 16) * 4;
+                    if (tot > lds_budget) continue;
+                    cc_ok = cc;
+                    break;
+                }
             }
-            const int want = g.d4 < 5 ? g.d4 : 5;
+            const int want = g.d4 < 5 ? 1 : 5;
             if (cc_ok >= want || (rb == 1 && cc_ok >= 1)) { bestRB = rb; bestCC = cc_ok; }
         }
     }
     if (!bestRB) return DIGAT_ERR_SHAPE;
     g.RB = bestRB; g.CC4 = bestCC; g.nchunks = g.d4 / g.CC4;
-    g.stage_f4 = g.RB * g.CC4 * g.NP;
-    const size_t stage = (size_t)4 * g.stage_f4 * 16;
+    g.img_slots = g.RB * 4 * g.NT * g.CC4;
+    g.ring_slots = (2 * g.img_slots + 63) / 64 * 64;
+    g.ninstr = g.ring_slots / 64;
+    const size_t ringb = (size_t)XA_RING * g.ring_slots * 16;
     const size_t sc = (size_t)g.RB * n * g.SN * 4;
-    g.am_off = (int)align_up(stage > sc ? stage : sc, 16);
-    g.ra_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
-    g.tl_off = g.ra_off + (g.RB + 1) * d * 4;
+    g.am_off = (int)align_up(ringb > sc ? ringb : sc, 16);
+    g.a_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
+    g.tl_off = g.a_off + d * 4;
     pl->lds = g.tl_off + ((size_t)g.RB * tiles + 16) * 4;
     pl->threads = threads;
     pl->blocks = (B + g.RB - 1) / g.RB;
     return DIGAT_OK;
 }
 
-static int launch_xattn_pairwise(const float* P, const float* Q, const float* h, const float* X, const float* r,
+// Pr = K3 + K1 (r already added to the neighbour-side projection), see xattn_core
+static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h, const float* X,
                                  const float* a, const uint8_t* A, float* out, float* alpha,
                                  int B, int n, int d, hipStream_t st) {
     XattnPlan pl;
     const int rc = plan_xattn(B, n, d, &pl);
     if (rc) return rc;
     if (B == 0) return DIGAT_OK;
-    pl.g.P = P; pl.g.Q = Q; pl.g.r = r; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha;
+    pl.g.P = Pr; pl.g.Q = Q; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha;
     {
         static int skip = -1;
         if (skip < 0) { const char* e = getenv("DIGAT_XATTN_SKIP"); skip = e ? atoi(e) : 0; }
         pl.g.skip = skip;
     }
     if (!(pl.g.skip & 32)) {
-        // algorithmic bytes of the score launch: P, Q in (2 n d floats), r, adjacency, alpha out, a
-        ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (2.0 * n * d * 4 + d * 4.0 + (double)n * n * 5.0) + 4.0 * d, st);
+        // algorithmic bytes of the score launch: P', Q in (2 n d floats), adjacency, alpha out, a
+        ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (2.0 * n * d * 4 + (double)n * n * 5.0) + 4.0 * d, st);
         if (pl.lds > 64 * 1024) {
             static int raised = 0;     // benign race: the attribute is idempotent
             if (!raised) {
@@ -1115,11 +1137,11 @@ size_t digat_xattn_workspace_bytes(int B, int n, int d) {
            + align_up((size_t)B * n * n * 4, 256);
 }
 
-int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X, const float* r,
+int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, const float* X,
                              const float* a, const uint8_t* A, float* out, float* alpha,
                              int B, int n, int d, void* stream) {
-    if (!P || !Q || !h || !X || !r || !a || !A || !out || !alpha) return DIGAT_ERR_ARG;
-    return launch_xattn_pairwise(P, Q, h, X, r, a, A, out, alpha, B, n, d, (hipStream_t)stream);
+    if (!Pr || !Q || !h || !X || !a || !A || !out || !alpha) return DIGAT_ERR_ARG;
+    return launch_xattn_pairwise(Pr, Q, h, X, a, A, out, alpha, B, n, d, (hipStream_t)stream);
 }
 
 // Eq. 8 layer with K3 (r = ctx F3^T + b3) already computed; `r_given` may live anywhere
@@ -1139,9 +1161,10 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
     g.nsegs = 3;
     g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
+    g.radd = r_given; g.radd_seg = 1; g.rows_per_b = n; // P' = K3 + K1: the reference's left-to-right order
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
-    return launch_xattn_pairwise(P, Q, h, X, r_given, a, A, out, alpha, B, n, d, st);
+    return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st);
 }
 
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,

@@ -69,12 +69,13 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
                     float* out, float* alpha_out, int B, int n, int d,
                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* The Eq. 8 pairwise part alone, on already-projected inputs (h = X W^T + bW, P = X F1^T,
- * Q = X F2^T, r = ctx F3^T + b3): score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j (written to
- * alpha [B,n,n], required) -> out = relu(alpha @ h) + X.  Two launches: the score kernel bench.py
- * prices against the HBM roofline, and the aggregation on the matrix cores. */
-int digat_xattn_pairwise_fwd(const float* P, const float* Q, const float* h, const float* X,
-                             const float* r, const float* a, const uint8_t* A,
+/* The Eq. 8 pairwise part alone, on already-projected inputs: h = X W^T + bW, Q = X F2^T and
+ * Pr = (ctx F3^T + b3) + X F1^T, i.e. K3 + K1 already summed in the reference's left-to-right order:
+ * score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j (written to alpha [B,n,n], required)
+ * -> out = relu(alpha @ h) + X.  Two launches: the score kernel bench.py prices against the HBM
+ * roofline, and the aggregation on the matrix cores. */
+int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, const float* X,
+                             const float* a, const uint8_t* A,
                              float* out, float* alpha, int B, int n, int d, void* stream);
 
 /* ---- a3: DIGAT.compute_news_graph_context  (graphEncoders.py:109-114, layers.py:199-206) ------

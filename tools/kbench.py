@@ -51,7 +51,7 @@ def bench_xattn(B=1024, n=67, d=400, density=None):
     L = _lib.lib()
 
     def run():
-        _lib.check(L.digat_xattn_pairwise_fwd(P.data_ptr(), Q.data_ptr(), h.data_ptr(), X.data_ptr(), r.data_ptr(),
+        _lib.check(L.digat_xattn_pairwise_fwd(P.data_ptr(), Q.data_ptr(), h.data_ptr(), X.data_ptr(),
                                               a.data_ptr(), A.data_ptr(), out.data_ptr(), alpha.data_ptr(), B, n, d,
                                               _lib.stream_ptr()), "xattn")
     med, best = timeit(run)
