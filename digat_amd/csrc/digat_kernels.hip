@@ -555,6 +555,10 @@ static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float
 // Tiles whose 16 adjacency bytes are all zero are never computed: a per-workgroup list of the
 // non-empty tiles is built from the adjacency image and threads are dealt tiles from that list, so
 // whole waves drop out on sparse graphs (masked scores are replaced by -1e9 whatever their value).
+// The kernel is VALU-bound (PMC: SQ_ACTIVE_INST_VALU ~ 96 % of the kernel, 4 cycles per wave64
+// instruction), so the inner loop uses a.relu(x) = (a.x + a.|x|)/2: per (i,j,c) one v_add (x = p + q) and
+// one v_fma with the free |x| source modifier instead of add + max + fma; the separable linear part
+// a.P'_j + a.Q_i is accumulated once per node by the first 8*NT*RB threads.
 // Scores go to LDS, one wave per (row, centre) does the masked softmax with shuffles and writes
 // alpha [B,n,n]; [B,n,n,d] is never materialised.
 struct ScoreArgs {
@@ -568,6 +572,7 @@ struct ScoreArgs {
     int am_off;        // byte offset of the adjacency bytes in LDS (16-B aligned image of the global bytes)
     int a_off;         // byte offset of a (d floats) in LDS
     int tl_off;        // byte offset of the non-empty-tile list (ints) + per-wave counters
+    int ld_off;        // byte offset of the per-node linear terms a.P'_j, a.Q_i (2 * RB * 4*NT floats)
     int skip;          // ablation only (env DIGAT_XATTN_SKIP, 0 in production): 1 no score loop,
                        // 2 no aggregation launch, 8 no softmax, 16 no empty-tile skipping, 32 no score launch
 };
@@ -605,6 +610,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     float4* a_lds = reinterpret_cast<float4*>(smem + g.a_off);
     int* tl = reinterpret_cast<int*>(smem + g.tl_off);     // [RB*NT*NT] tile list, then [16] wave counts
     int* wcnt = tl + g.RB * NT * NT;
+    float* lin = reinterpret_cast<float*>(smem + g.ld_off);   // [2][RB][4*NT]: a.P'_node, a.Q_node by image position
     const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     // ---- this wave's DMA pieces: instruction q = wave + nwaves*k covers image slots [64q, 64q+64)
@@ -710,6 +716,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
 
+    const int lin_rows = 2 * g.RB * 4 * NT;       // image rows: P' rows of every row-block, then Q rows
+    float ldot = 0.f;                               // thread tid < lin_rows: a . (image row tid)
     for (int ch = 0; ch < g.nchunks; ++ch) {
         // chunk ch has landed once at most the newer chunk's pieces of THIS wave are outstanding ...
         wait_vmcnt(ch + 1 < g.nchunks ? kw : 0);
@@ -731,16 +739,25 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        float sc = acc[ii][jj];
-                        sc = fmaf(a4.x, fmaxf(p[jj].x + q[ii].x, 0.f), sc);
-                        sc = fmaf(a4.y, fmaxf(p[jj].y + q[ii].y, 0.f), sc);
-                        sc = fmaf(a4.z, fmaxf(p[jj].z + q[ii].z, 0.f), sc);
-                        sc = fmaf(a4.w, fmaxf(p[jj].w + q[ii].w, 0.f), sc);
+                        float sc = acc[ii][jj];          // accumulates sum_c a_c |x_c|
+                        sc = fmaf(a4.x, fabsf(p[jj].x + q[ii].x), sc);
+                        sc = fmaf(a4.y, fabsf(p[jj].y + q[ii].y), sc);
+                        sc = fmaf(a4.z, fabsf(p[jj].z + q[ii].z), sc);
+                        sc = fmaf(a4.w, fabsf(p[jj].w + q[ii].w), sc);
                         acc[ii][jj] = sc;
                     }
             }
         }
+        if (tid < lin_rows) {   // the separable part sum_c a_c (P'_jc + Q_ic), once per node
+            const float4* row = ring + (ch % XA_RING) * g.ring_slots + tid * CC4;      // P' rows then Q rows: contiguous
+            const float4* av = a_lds + ch * CC4;
+            for (int c4 = 0; c4 < CC4; ++c4) {
+                const float4 v = row[c4], a4 = av[c4];
+                ldot = fmaf(a4.w, v.w, fmaf(a4.z, v.z, fmaf(a4.y, v.y, fmaf(a4.x, v.x, ldot))));
+            }
+        }
     }
+    if (tid < lin_rows) lin[tid] = ldot;
     __syncthreads();            // every wave is done with the ring: Ss may alias it
 
     // ---- phase 2a: every score starts masked (-1e9, not -inf)
@@ -757,7 +774,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                 const int j = 4 * tj + jj;
                 if (j >= n) continue;
                 if (Am[(rb_t * n + i) * n + j] != 0) {
-                    const float e = acc[ii][jj];
+                    // a.relu(x) = (a.x + a.|x|) / 2
+                    const float e = 0.5f * (acc[ii][jj] + (lin[rb_t * 4 * NT + jj * NT + tj]
+                                                          + lin[(g.RB + rb_t) * 4 * NT + ii * NT + ti]));
                     Ss[(rb_t * n + i) * SN + j] = e > 0.f ? e : 0.2f * e;
                 }
             }
@@ -905,7 +924,8 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
                     const size_t sc = (size_t)rb * n * g.SN * 4;
                     const size_t ringb = (size_t)XA_RING * ring_slots * 16;
                     const size_t tot = align_up(ringb > sc ? ringb : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
-                                       + (size_t)d * 4 + ((size_t)rb * tiles + 16) * 4;
+                                       + (size_t)d * 4 + ((size_t)rb * tiles + 16) * 4 + (size_t)rb * 8 * g.NT * 4;
+                    if (2 * rb * 4 * g.NT > threads) continue;           // one thread per image row for the linear terms
                     if (tot > lds_budget) continue;
                     cc_ok = cc;
                     break;
@@ -925,7 +945,8 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     g.am_off = (int)align_up(ringb > sc ? ringb : sc, 16);
     g.a_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
     g.tl_off = g.a_off + d * 4;
-    pl->lds = g.tl_off + ((size_t)g.RB * tiles + 16) * 4;
+    g.ld_off = g.tl_off + (g.RB * tiles + 16) * 4;
+    pl->lds = g.ld_off + (size_t)g.RB * 8 * g.NT * 4;
     pl->threads = threads;
     pl->blocks = (B + g.RB - 1) / g.RB;
     return DIGAT_OK;
