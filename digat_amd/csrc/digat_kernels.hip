@@ -555,6 +555,11 @@ static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float
 // Tiles whose 16 adjacency bytes are all zero are never computed: a per-workgroup list of the
 // non-empty tiles is built from the adjacency image and threads are dealt tiles from that list, so
 // whole waves drop out on sparse graphs (masked scores are replaced by -1e9 whatever their value).
+// To make empty tiles common, the nodes of every row are first ORDERED by their first neighbour
+// (stable rank sort in LDS): same-category history items and their topic node share that key, so the
+// adjacency becomes block-diagonal.  The order only changes which node a tile slot holds (DMA source
+// address, adjacency lookup); alpha is written in the caller's node order and its values do not depend
+// on the order (each score is one thread's sequential channel sum).
 // The kernel is VALU-bound (PMC: SQ_ACTIVE_INST_VALU ~ 96 % of the kernel, 4 cycles per wave64
 // instruction), so the inner loop uses a.relu(x) = (a.x + a.|x|)/2: per (i,j,c) one v_add (x = p + q) and
 // one v_fma with the free |x| source modifier instead of add + max + fma; the separable linear part
@@ -569,10 +574,11 @@ struct ScoreArgs {
     int img_slots;     // float4 slots of one operand image of one chunk = RB * 4*NT * CC4
     int ring_slots;    // slots of one ring buffer: both operands, padded to a multiple of 64
     int ninstr;        // DMA wave-instructions per chunk = ring_slots / 64
-    int am_off;        // byte offset of the adjacency bytes in LDS (16-B aligned image of the global bytes)
+    int am_off;        // byte offset of the adjacency BIT rows in LDS: [RB*n][NW] words, NW = ceil(n/32)
     int a_off;         // byte offset of a (d floats) in LDS
     int tl_off;        // byte offset of the non-empty-tile list (ints) + per-wave counters
     int ld_off;        // byte offset of the per-node linear terms a.P'_j, a.Q_i (2 * RB * 4*NT floats)
+    int pm_off;        // byte offset of the node permutation: keys [RB*n] ints, then node_of [RB*n] ints
     int skip;          // ablation only (env DIGAT_XATTN_SKIP, 0 in production): 1 no score loop,
                        // 2 no aggregation launch, 8 no softmax, 16 no empty-tile skipping, 32 no score launch
 };
@@ -606,12 +612,67 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 
     float4* ring = reinterpret_cast<float4*>(smem);        // [XA_RING][ring_slots]: P' image, then Q image
     float* Ss = reinterpret_cast<float*>(smem);            // [RB][n][SN], aliases the ring after the chunk loop
-    uint8_t* Am = smem + g.am_off;                         // [RB][n*n] (+ alignment slack)
+    unsigned* Ab = reinterpret_cast<unsigned*>(smem + g.am_off);   // adjacency bit rows [RB*n][NW]
+    const int NW = (n + 31) >> 5;
     float4* a_lds = reinterpret_cast<float4*>(smem + g.a_off);
     int* tl = reinterpret_cast<int*>(smem + g.tl_off);     // [RB*NT*NT] tile list, then [16] wave counts
     int* wcnt = tl + g.RB * NT * NT;
     float* lin = reinterpret_cast<float*>(smem + g.ld_off);   // [2][RB][4*NT]: a.P'_node, a.Q_node by image position
     const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- phase 0: the adjacency bytes pass through the (still idle) ring area with wide loads and are
+    // condensed to bit rows; the score vector a goes to LDS
+    {
+        // 16-byte loads from the enclosing aligned window
+        const uint8_t* src = g.A + (long)b0 * n * n;
+        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+        const uint4* src16 = reinterpret_cast<const uint4*>(src - mis);
+        const int nvec = (rows_here * n * n + mis + 15) >> 4;
+        uint4* dst16 = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < nvec; i += nthreads) dst16[i] = src16[i];
+        const float4* a4 = reinterpret_cast<const float4*>(g.a);
+        for (int i = tid; i < d4; i += nthreads) a_lds[i] = a4[i];
+        __syncthreads();
+        const uint8_t* bytes = smem + mis;
+        for (int e = tid; e < rows_here * n * NW; e += nthreads) {
+            const int row = e / NW, w = e - row * NW;
+            unsigned bits = 0;
+            const uint8_t* br = bytes + row * n + w * 32;
+            const int lim = min(32, n - w * 32);
+            for (int k = 0; k < lim; ++k) bits |= (br[k] != 0 ? 1u : 0u) << k;
+            Ab[e] = bits;
+        }
+    }
+    __syncthreads();
+    auto edge = [&](int rb, int i, int j) -> bool { return (Ab[(rb * n + i) * NW + (j >> 5)] >> (j & 31)) & 1u; };
+
+    // ---- node order: stable sort of each row's nodes by their first neighbour (block-diagonalises the
+    // category structure of user graphs; any order is legal)
+    int* keys = reinterpret_cast<int*>(smem + g.pm_off);       // [RB*n]
+    int* node_of = keys + g.RB * n;                            // [RB*n]: node held by sorted slot sig
+    for (int e = tid; e < rows_here * n; e += nthreads) {
+        const int rb = e / n, i = e - rb * n;
+        int key = i;
+        if (!(g.skip & 16)) {
+            for (int w = 0; w < NW; ++w) {
+                const unsigned bits = Ab[e * NW + w];
+                if (bits) { key = w * 32 + __ffs(bits) - 1; break; }
+            }
+        }
+        keys[e] = key;
+    }
+    __syncthreads();
+    for (int e = tid; e < rows_here * n; e += nthreads) {
+        const int rb = e / n, i = e - rb * n;
+        const int key = keys[e];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) {
+            const int kk = keys[rb * n + k];
+            rank += (kk < key) || (kk == key && k < i);
+        }
+        node_of[rb * n + rank] = i;
+    }
+    __syncthreads();
 
     // ---- this wave's DMA pieces: instruction q = wave + nwaves*k covers image slots [64q, 64q+64)
     const float* Pblk = g.P + (long)b0 * n * g.d;
@@ -632,9 +693,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             int rb = e / per_row;
             const int rem = e - rb * per_row;
             const int pos = rem / CC4, c4 = rem - pos * CC4;
-            int node = (pos % NT) * 4 + pos / NT;
-            if (node >= n) node = n - 1;                                       // padding positions: any real node
+            int sig = (pos % NT) * 4 + pos / NT;                               // sorted slot held by this image position
+            if (sig >= n) sig = n - 1;                                         // padding positions: any real node
             if (rb >= rows_here) rb = rows_here - 1;
+            const int node = node_of[rb * n + sig];
             src_off[k] = ((rb * n + node) * g.d + c4 * 4) | (op << 31);
         }
     }
@@ -652,21 +714,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     issue(0, 0);
     if (g.nchunks > 1) issue(1, 1);
 
-    // ---- phase 0: adjacency bytes and the score vector a go to LDS with wide loads
-    {
-        // 16-byte loads from the enclosing aligned window; Am points at the first real byte
-        const uint8_t* src = g.A + (long)b0 * n * n;
-        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
-        const uint4* src16 = reinterpret_cast<const uint4*>(src - mis);
-        const int nvec = (rows_here * n * n + mis + 15) >> 4;
-        uint4* dst16 = reinterpret_cast<uint4*>(smem + g.am_off);
-        for (int i = tid; i < nvec; i += nthreads) dst16[i] = src16[i];
-        Am += mis;
-        const float4* a4 = reinterpret_cast<const float4*>(g.a);
-        for (int i = tid; i < d4; i += nthreads) a_lds[i] = a4[i];
-    }
-    __syncthreads();            // (also drains the first DMA pieces; the loop's counted waits take over below)
-
     // ---- non-empty tiles -> compact list (order = tile id, deterministic)
     const int tiles = NT * NT;
     int my_tile = -1;
@@ -681,11 +728,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             } else {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const int i = 4 * ti + ii;
+                    const int si = 4 * ti + ii;
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const int j = 4 * tj + jj;
-                        if (i < n && j < n && Am[(rb * n + i) * n + j] != 0) flag = true;
+                        const int sj = 4 * tj + jj;
+                        if (si < n && sj < n && edge(rb, node_of[rb * n + si], node_of[rb * n + sj])) flag = true;
                     }
                 }
             }
@@ -767,13 +814,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     if (active) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * ti + ii;
-            if (i >= n) continue;
+            if (4 * ti + ii >= n) continue;
+            const int i = node_of[rb_t * n + 4 * ti + ii];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int j = 4 * tj + jj;
-                if (j >= n) continue;
-                if (Am[(rb_t * n + i) * n + j] != 0) {
+                if (4 * tj + jj >= n) continue;
+                const int j = node_of[rb_t * n + 4 * tj + jj];
+                if (edge(rb_t, i, j)) {
                     // a.relu(x) = (a.x + a.|x|) / 2
                     const float e = 0.5f * (acc[ii][jj] + (lin[rb_t * 4 * NT + jj * NT + tj]
                                                           + lin[(g.RB + rb_t) * 4 * NT + ii * NT + ti]));
@@ -923,8 +970,10 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
                     if ((size_t)XA_RING * ring_slots * 16 > 60 * 1024) continue;
                     const size_t sc = (size_t)rb * n * g.SN * 4;
                     const size_t ringb = (size_t)XA_RING * ring_slots * 16;
-                    const size_t tot = align_up(ringb > sc ? ringb : sc, 16) + align_up((size_t)rb * n * n, 16) + 16
-                                       + (size_t)d * 4 + ((size_t)rb * tiles + 16) * 4 + (size_t)rb * 8 * g.NT * 4;
+                    if ((size_t)rb * n * n + 32 > ringb) continue;          // the byte image passes through the ring area
+                    const size_t tot = align_up(ringb > sc ? ringb : sc, 16) + (size_t)rb * n * ((n + 31) / 32) * 4
+                                       + (size_t)d * 4 + ((size_t)rb * tiles + 16) * 4 + (size_t)rb * 8 * g.NT * 4
+                                       + (size_t)2 * rb * n * 4;
                     if (2 * rb * 4 * g.NT > threads) continue;           // one thread per image row for the linear terms
                     if (tot > lds_budget) continue;
                     cc_ok = cc;
@@ -943,10 +992,11 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     const size_t ringb = (size_t)XA_RING * g.ring_slots * 16;
     const size_t sc = (size_t)g.RB * n * g.SN * 4;
     g.am_off = (int)align_up(ringb > sc ? ringb : sc, 16);
-    g.a_off = g.am_off + (int)align_up((size_t)g.RB * n * n, 16) + 16;      // +16: misalignment slack
+    g.a_off = g.am_off + (int)align_up((size_t)g.RB * n * ((n + 31) / 32) * 4, 16);
     g.tl_off = g.a_off + d * 4;
     g.ld_off = g.tl_off + (g.RB * tiles + 16) * 4;
-    pl->lds = g.ld_off + (size_t)g.RB * 8 * g.NT * 4;
+    g.pm_off = g.ld_off + g.RB * 8 * g.NT * 4;
+    pl->lds = g.pm_off + (size_t)2 * g.RB * n * 4;
     pl->threads = threads;
     pl->blocks = (B + g.RB - 1) / g.RB;
     return DIGAT_OK;
