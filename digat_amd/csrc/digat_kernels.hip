@@ -489,9 +489,131 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
     }
 }
 
+// =================================================================================================
+// 1c. skinny linear for the [B,d] projections (M < 2048): a latency chain, not a throughput problem
+// =================================================================================================
+// 32x80 output tile per workgroup; the four waves split K (16-wide k blocks, wave w takes blocks
+// w, w+4, ...) and load their MFMA operand fragments straight from global memory as float4 — lane
+// (row l&15, quarter q) holds k = 16*kb + 4q .. +3 of its row and feeds element s to the s-th
+// v_mfma_f32_16x16x4_f32 k-step, for A and B alike — with the next block's loads in flight under the
+// current block's 40 MFMAs.  No LDS staging, no barrier in the K loop; one LDS reduction at the end.
+// A may be two K-segments split at a multiple of 16 (the gate's [local ; global]); epilogues as gemm_f32.
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
+    __shared__ float red[4][40][64];
+    const int tile = blockIdx.x;
+    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int m0 = mtile * 32, n0 = ntile * 80;
+    const int seg = n0 / g.nseg;
+    const int nbase = n0 - seg * g.nseg;
+    const float* const wseg = g.w[seg];
+    const int nkb = (g.K + 15) >> 4;
+
+    const float* arow[2][2];     // [mt][A segment]
+    bool aok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int gm = m0 + mt * 16 + lr;
+        aok[mt] = gm < g.M;
+        arow[mt][0] = g.a0 + (long)(aok[mt] ? gm : 0) * g.lda0;
+        arow[mt][1] = g.a1 ? g.a1 + (long)(aok[mt] ? gm : 0) * g.lda1 : arow[mt][0];
+    }
+    const float* brow[5];
+    bool bok[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+        const int nn = nbase + nt * 16 + lr;
+        bok[nt] = nn < g.nseg;
+        brow[nt] = wseg + (long)(bok[nt] ? nn : 0) * g.K;
+    }
+    auto load_block = [&](int kb, float4* a, float4* b) {
+        const int k = kb * 16 + 4 * lq;
+        const bool kin = k < g.K;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float* p = k < g.k0 ? arow[mt][0] + k : arow[mt][1] + (k - g.k0);
+            a[mt] = (kin && aok[mt]) ? *reinterpret_cast<const float4*>(p) : f4_zero();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt)
+            b[nt] = (kin && bok[nt]) ? *reinterpret_cast<const float4*>(brow[nt] + k) : f4_zero();
+    };
+
+    v4f acc[2][5];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    float4 a0[2], b0[5], a1[2], b1[5];
+    int kb = wave;
+    if (kb < nkb) load_block(kb, a0, b0);
+    while (kb < nkb) {
+        const int kn = kb + 4;
+        if (kn < nkb) load_block(kn, a1, b1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_comp(a0[mt], s), f4_comp(b0[nt], s), acc[mt][nt], 0, 0, 0);
+        kb = kn;
+        if (kb >= nkb) break;
+        const int kn2 = kb + 4;
+        if (kn2 < nkb) load_block(kn2, a0, b0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_comp(a1[mt], s), f4_comp(b1[nt], s), acc[mt][nt], 0, 0, 0);
+        kb = kn2;
+    }
+    // K-split reduction in wave order 0..3 (deterministic); wave w finalises accumulator registers [10w, 10w+10)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(mt * 5 + nt) * 4 + r][lane] = acc[mt][nt][r];
+    __syncthreads();
+    const float* bp = g.bias[seg];
+    float* yp = g.y[seg];
+    for (int q = 0; q < 10; ++q) {
+        const int reg = wave * 10 + q;
+        const int mt = reg / 20, nt = (reg / 4) % 5, r = reg & 3;
+        const int gm = m0 + mt * 16 + lq * 4 + r;
+        const int nn = nbase + nt * 16 + lr;
+        if (gm >= g.M || nn >= g.nseg) continue;
+        float v = ((red[0][reg][lane] + red[1][reg][lane]) + red[2][reg][lane]) + red[3][reg][lane];
+        v += bp ? bp[nn] : 0.f;
+        if (g.epi == EPI_RELU_RES) {
+            v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
+        } else if (g.epi == EPI_GATE) {
+            const float gate = 1.f / (1.f + expf(-v));
+            const float loc = g.e0[(long)gm * g.lde0 + nn];
+            const float glo = g.e1[(long)gm * g.lde1 + nn];
+            v = gate * loc + (1.f - gate) * glo;
+            if (g.e2) v = g.e2[(long)gm * g.lde2 + nn] + v;
+        }
+        yp[(long)gm * g.ldy + nn] = v;
+    }
+}
+
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
+    if (g.M < 2048 && g.nseg % 80 == 0 && !g.transW && g.K % 4 == 0 && g.k0 % 16 == 0 && !g.radd) {
+        ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
+        g.mtiles = (g.M + 31) / 32;
+        g.ntiles = Ntot / 80;
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(g.mtiles * g.ntiles), dim3(256), 0, st, g);
+        DIGAT_CHECK_LAUNCH();
+        return DIGAT_OK;
+    }
     // tile configuration: 128x80 for the big projections; below 2048 rows 32x64 (most workgroups), or
     // 64x80 for multi-segment launches whose segments are multiples of 80 columns (d = 400); the small-M
     // shapes keep two K tiles in flight
