@@ -61,6 +61,27 @@ _SIGNATURES = {
     "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f]),
     "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
     "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),
+    "digat_linear_bwd_input": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_linear_bwd_weight_workspace": (C.c_size_t, [C.c_int] * 3),
+    "digat_linear_bwd_weight": (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f,
+                                          C.c_size_t, _f]),
+    "digat_colsum": (C.c_int, [_f, C.c_int64, _f, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_dropout_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_float, C.c_uint32, _f]),
+    "digat_dropout_bwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_float, _f]),
+    "digat_gate_fwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f]),
+    "digat_gate_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, _f, _f, _f, C.c_int, C.c_int, _f]),
+    "digat_relu_res_fwd": (C.c_int, [_f, _f, _f, C.c_int64, _f]),
+    "digat_relu_mask": (C.c_int, [_f, _f, _f, C.c_int64, _f]),
+    "digat_attn_pool_fwd": (C.c_int, [_f, C.c_int64, _f, _f, _f, _f, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_attn_pool_bwd": (C.c_int, [_f, C.c_int64, _f, _f, _f, _f, _f, C.c_int64, _f, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _f]),
+    "digat_topic_pool_fwd_train": (C.c_int, [_f] * 5 + [C.c_int] * 5 + [_f]),
+    "digat_topic_pool_bwd": (C.c_int, [_f] * 7 + [C.c_int] * 5 + [_f]),
+    "digat_xattn_project": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f]),
+    "digat_xattn_pairwise_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_xattn_pairwise_bwd_workspace": (C.c_size_t, [C.c_int] * 3),
+    "digat_xattn_pairwise_bwd": (C.c_int, [_f] * 11 + [C.c_float] + [_f] * 4 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
+    "digat_sum_nodes": (C.c_int, [_f, _f, C.c_int, C.c_int, C.c_int, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // =================================================================================================
 // 1. fp32 MFMA GEMM:  y_s[M, nseg] = A[M,K] @ w_s[nseg,K]^T (+ bias_s), s < nsegs, fused epilogue
 // =================================================================================================
-enum { EPI_NONE = 0, EPI_RELU_RES = 1, EPI_GATE = 2 };
+enum { EPI_NONE = 0, EPI_RELU_RES = 1, EPI_GATE = 2, EPI_ACCUM = 3 };   // ACCUM: y += result (backward sums)
 
 struct GemmArgs {
     const float* a0; long lda0; int k0;      // columns [0,k0) of A come from a0 ...
@@ -281,6 +281,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                     const float glo = g.e1[(long)gm * g.lde1 + nn];
                     v = gate * loc + (1.f - gate) * glo;
                     if (g.e2) v = g.e2[(long)gm * g.lde2 + nn] + v;
+                } else if (g.epi == EPI_ACCUM) {
+                    v = yp[(long)gm * g.ldy + nn] + v;
                 }
                 yp[(long)gm * g.ldy + nn] = v;
             }
@@ -598,6 +600,8 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
             const float glo = g.e1[(long)gm * g.lde1 + nn];
             v = gate * loc + (1.f - gate) * glo;
             if (g.e2) v = g.e2[(long)gm * g.lde2 + nn] + v;
+        } else if (g.epi == EPI_ACCUM) {
+            v = yp[(long)gm * g.ldy + nn] + v;
         }
         yp[(long)gm * g.ldy + nn] = v;
     }
@@ -691,6 +695,7 @@ static GemmArgs gemm_plain(const float* x, long ldx, const float* w, const float
 struct ScoreArgs {
     const float* P;    // P' = r + P  (K3 + K1)
     const float* Q; const float* a; const uint8_t* A; float* alpha;
+    float* s_out;      // optional [B,n,n]: scores before leaky_relu / mask on the edges (training)
     int B, n, d, d4;
     int NT, SN, CC4, nchunks, RB;
     int img_slots;     // float4 slots of one operand image of one chunk = RB * 4*NT * CC4
@@ -946,6 +951,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                     // a.relu(x) = (a.x + a.|x|) / 2
                     const float e = 0.5f * (acc[ii][jj] + (lin[rb_t * 4 * NT + jj * NT + tj]
                                                           + lin[(g.RB + rb_t) * 4 * NT + ii * NT + ti]));
+                    if (g.s_out) g.s_out[((long)(b0 + rb_t) * n + i) * n + j] = e;
                     Ss[(rb_t * n + i) * SN + j] = e > 0.f ? e : 0.2f * e;
                 }
             }
@@ -1172,6 +1178,7 @@ struct PoolArgs {
     const float* feat; long ld_b;        // feat[b] = feat + b*ld_b, nodes are d floats apart
     const float* kq; const uint8_t* mask; const float* addend; float* out;
     int B, n, d; float sqrt_d;
+    float* alpha_out;                    // optional [B,n]: the attention weights (training)
 };
 
 __global__ void __launch_bounds__(256) attn_pool_kernel(const PoolArgs g) {
@@ -1199,6 +1206,10 @@ __global__ void __launch_bounds__(256) attn_pool_kernel(const PoolArgs g) {
         const float s = wave_sum(e0 + e1);
         if (lane < n) sc[lane] = e0 / s;
         if (lane + 64 < n) sc[lane + 64] = e1 / s;
+        if (g.alpha_out) {
+            if (lane < n) g.alpha_out[(long)b * n + lane] = e0 / s;
+            if (lane + 64 < n) g.alpha_out[(long)b * n + lane + 64] = e1 / s;
+        }
     }
     __syncthreads();
     for (int c4 = tid; c4 < d4; c4 += 256) {
@@ -1217,7 +1228,7 @@ static int launch_pool(const float* feat, long ld_b, const float* kq, const uint
                        float* out, int B, int n, int d, hipStream_t st) {
     if (n > DIGAT_MAX_NODES || d % 4) return DIGAT_ERR_SHAPE;
     if (B == 0) return DIGAT_OK;
-    PoolArgs g{feat, ld_b, kq, mask, addend, out, B, n, d, sqrtf((float)d)};
+    PoolArgs g{feat, ld_b, kq, mask, addend, out, B, n, d, sqrtf((float)d), nullptr};
     ProfScope prof(DIGAT_KERNEL_POOL, (double)B * ((double)n * d * 4 + 2.0 * d * 4 + n), st);
     hipLaunchKernelGGL(attn_pool_kernel, dim3(B), dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
@@ -1230,6 +1241,7 @@ static int launch_pool(const float* feat, long ld_b, const float* kq, const uint
 struct TopicArgs {
     const float* Xu; long ld_b; const float* kq; const int64_t* idx; float* out;
     int B, H, C1, d; float sqrt_d;
+    float* alpha_out;                    // optional [B,H]: the segment-softmax weights (training)
 };
 constexpr int TOPIC_MAX_H = 256;
 
@@ -1262,6 +1274,7 @@ __global__ void __launch_bounds__(256) topic_pool_kernel(const TopicArgs g) {
         float den = 0.f;
         for (int u = 0; u < H; ++u) if (sidx[u] == s) den += expf(sa[u] - m);
         sal[t] = s >= 0 ? expf(sa[t] - m) / den : 0.f;
+        if (g.alpha_out) g.alpha_out[(long)b * H + t] = sal[t];
     }
     __syncthreads();
     // out[c][:] = sum over t with idx_t == c, in ascending t (the CPU scatter_add order)
@@ -1285,7 +1298,7 @@ static int launch_topic(const float* Xu, long ld_b, const float* kq, const int64
                         int B, int H, int C1, int d, hipStream_t st) {
     if (H > TOPIC_MAX_H || d % 4) return DIGAT_ERR_SHAPE;
     if (B == 0) return DIGAT_OK;
-    TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d)};
+    TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d), nullptr};
     ProfScope prof(DIGAT_KERNEL_TOPIC, (double)B * ((double)H * d * 4 + d * 4.0 + H * 8.0 + (double)C1 * d * 4), st);
     hipLaunchKernelGGL(topic_pool_kernel, dim3(B), dim3(256), 0, st, g);
     DIGAT_CHECK_LAUNCH();
@@ -1771,3 +1784,5 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 }
 
 }  // extern "C"
+
+#include "digat_train.inc"

@@ -1,12 +1,355 @@
-"""Training-mode forward of the DIGAT encoder (autograd through the HIP path).
+"""Training-mode forward of the DIGAT encoder: autograd through native HIP forward/backward pairs.
 
-Not implemented in this revision: the backward kernels (digat_xattn_bwd & co., SURVEY.md §8b item
-2) are the next row of the scope table.  Failing loudly here is deliberate — there is no eager
-PyTorch fallback that could silently stand in for the native path.
+The reference trains by plain autograd through ``graphEncoders.DIGAT.forward`` (trainer.py:98-102).
+Here the same forward (graphEncoders.py:177-187, with its three dropouts live) is composed from a small
+set of ``torch.autograd.Function``s whose forward AND backward are kernels of ``libdigat_hip.so``:
+
+    Linear / MatmulW      nn.Linear and x @ K (the folded-away key projection, unfolded for training)
+    AttnPool, TopicPool   ScaledDotProductAttention pooling, scatter_softmax + scatter_sum
+    GateMix, ReluRes      sigmoid gate mix, relu(y) + t
+    Dropout               counter-hash dropout (own RNG: masks differ from torch's, statistics do not)
+    XattnLayer            Eq. 8: projections + score/softmax/aggregate; the backward RECOMPUTES
+                          relu'(K3+K1+K2) from the saved projections, [B,n,n,d] is never stored
+
+PyTorch does what it does for the reference too: owns the tensors, records the graph, and runs the
+few pure data-movement ops (``cat``, ``select``, ``expand``, ``+`` of two contexts).  There is no
+eager fallback for any arithmetic of the path: every Function raises through ``_lib.check``.
 """
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+L = _lib.lib
+S = _lib.stream_ptr
 
 
-def digat_forward_train(encoder, *inputs):
-    raise NotImplementedError(
-        "digat_amd: training-mode forward/backward through the HIP kernels is not implemented yet; "
-        "use model.eval() / torch.no_grad() for the inference path")
+def _seed() -> int:
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+def _f(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if not t.is_contiguous() else t
+
+
+def _rows(x: torch.Tensor):
+    """(tensor, M, K, ld): x viewed as M rows of K contiguous floats, row stride ld."""
+    if x.dim() == 2 and x.stride(1) == 1:
+        return x, x.shape[0], x.shape[1], x.stride(0)
+    x = _f(x)
+    K = x.shape[-1]
+    return x, x.numel() // K, K, K
+
+
+class Linear(Function):
+    """y = x W^T + b  (W [N,K] as in nn.Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x, M, K, ld = _rows(x)
+        N = W.shape[0]
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        if M:
+            _lib.check(L().digat_linear_f32(x.data_ptr(), ld, W.data_ptr(), _lib.ptr(b), y.data_ptr(), N, M, N, K, S()),
+                       "digat_linear_f32")
+        ctx.save_for_backward(x, W)
+        ctx.dims = (M, N, K, ld, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        M, N, K, ld, has_b = ctx.dims
+        dy = _f(dy)
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        dW = torch.empty_like(W)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
+        if M:
+            _lib.check(L().digat_linear_bwd_input(dy.data_ptr(), N, W.data_ptr(), dx.data_ptr(), K, M, N, K, 0, S()),
+                       "digat_linear_bwd_input")
+            nb = L().digat_linear_bwd_weight_workspace(M, N, K)
+            ws = _lib.workspace(nb, x.device, "dW")
+            _lib.check(L().digat_linear_bwd_weight(dy.data_ptr(), N, x.data_ptr(), ld, dW.data_ptr(), _lib.ptr(db), M, N, K, 0,
+                                                   ws.data_ptr(), nb, S()), "digat_linear_bwd_weight")
+        else:
+            dx.zero_(); dW.zero_()
+            if db is not None:
+                db.zero_()
+        return dx, dW, db
+
+
+class MatmulW(Function):
+    """y[M,K] = x[M,N] @ W[N,K]   (kq = q @ K.weight: the key projection moved onto the query)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _f(x)
+        M, N = x.shape
+        K = W.shape[1]
+        y = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        _lib.check(L().digat_linear_bwd_input(x.data_ptr(), N, W.data_ptr(), y.data_ptr(), K, M, N, K, 0, S()), "matmul_w")
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f(dy)
+        M, N = x.shape
+        K = W.shape[1]
+        dx = torch.empty_like(x)
+        dW = torch.empty_like(W)
+        # dx = dy @ W^T  -> linear(dy, W);  dW[n][k] = sum_m x[m][n] dy[m][k]
+        _lib.check(L().digat_linear_f32(dy.data_ptr(), K, W.data_ptr(), None, dx.data_ptr(), N, M, N, K, S()), "matmul_w dx")
+        nb = L().digat_linear_bwd_weight_workspace(M, N, K)
+        ws = _lib.workspace(nb, x.device, "dW")
+        _lib.check(L().digat_linear_bwd_weight(x.data_ptr(), N, dy.data_ptr(), K, dW.data_ptr(), None, M, N, K, 0,
+                                               ws.data_ptr(), nb, S()), "matmul_w dW")
+        return dx, dW
+
+
+class Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(L().digat_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), _seed(), S()),
+                   "digat_dropout_fwd")
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f(dy)
+        dx = torch.empty_like(dy)
+        _lib.check(L().digat_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, S()),
+                   "digat_dropout_bwd")
+        return dx, None
+
+
+def dropout(x, p, training=True):
+    return Dropout.apply(x, p) if (training and p > 0) else x
+
+
+class AttnPool(Function):
+    """ScaledDotProductAttention pooling with the folded query kq: out = sum_j softmax(x_j.kq/sqrt(d)) x_j."""
+
+    @staticmethod
+    def forward(ctx, feat, kq, mask):
+        feat, kq = _f(feat), _f(kq)
+        B, n, d = feat.shape
+        out = torch.empty((B, d), dtype=torch.float32, device=feat.device)
+        alpha = torch.empty((B, n), dtype=torch.float32, device=feat.device)
+        _lib.check(L().digat_attn_pool_fwd(feat.data_ptr(), n * d, kq.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                           alpha.data_ptr(), B, n, d, S()), "digat_attn_pool_fwd")
+        ctx.save_for_backward(feat, kq, mask, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, kq, mask, alpha = ctx.saved_tensors
+        B, n, d = feat.shape
+        dout = _f(dout)
+        dfeat = torch.empty_like(feat)
+        dkq = torch.empty_like(kq)
+        _lib.check(L().digat_attn_pool_bwd(feat.data_ptr(), n * d, kq.data_ptr(), mask.data_ptr(), alpha.data_ptr(),
+                                           dout.data_ptr(), dfeat.data_ptr(), n * d, dkq.data_ptr(), B, n, d, 0, S()),
+                   "digat_attn_pool_bwd")
+        return dfeat, dkq, None
+
+
+class TopicPool(Function):
+    """scatter_softmax + scatter_sum over the first H rows of Xu grouped by category (graphEncoders.py:126-130)."""
+
+    @staticmethod
+    def forward(ctx, Xu, kq, idx, H, C1):
+        Xu, kq = _f(Xu), _f(kq)
+        B, U, d = Xu.shape
+        T = torch.empty((B, C1, d), dtype=torch.float32, device=Xu.device)
+        alpha = torch.empty((B, H), dtype=torch.float32, device=Xu.device)
+        _lib.check(L().digat_topic_pool_fwd_train(Xu.data_ptr(), kq.data_ptr(), idx.data_ptr(), T.data_ptr(), alpha.data_ptr(),
+                                                  B, U, H, C1, d, S()), "digat_topic_pool_fwd_train")
+        ctx.save_for_backward(Xu, kq, idx, alpha)
+        ctx.dims = (H, C1)
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        Xu, kq, idx, alpha = ctx.saved_tensors
+        H, C1 = ctx.dims
+        B, U, d = Xu.shape
+        dT = _f(dT)
+        dXu = torch.zeros_like(Xu)              # topic rows receive no gradient from the pooling
+        dkq = torch.empty_like(kq)
+        _lib.check(L().digat_topic_pool_bwd(Xu.data_ptr(), kq.data_ptr(), idx.data_ptr(), alpha.data_ptr(), dT.data_ptr(),
+                                            dXu.data_ptr(), dkq.data_ptr(), B, U, H, C1, d, S()), "digat_topic_pool_bwd")
+        return dXu, dkq, None, None, None
+
+
+class GateMix(Function):
+    """out = sigmoid(z) * l + (1 - sigmoid(z)) * g   (graphEncoders.py:112-113)."""
+
+    @staticmethod
+    def forward(ctx, z, l, g):
+        z, l, g = _f(z), _f(l), _f(g)
+        B, d = z.shape
+        out = torch.empty_like(z)
+        _lib.check(L().digat_gate_fwd(z.data_ptr(), l.data_ptr(), d, g.data_ptr(), out.data_ptr(), B, d, S()), "digat_gate_fwd")
+        ctx.save_for_backward(z, l, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, l, g = ctx.saved_tensors
+        B, d = z.shape
+        dout = _f(dout)
+        dz, dl, dg = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        _lib.check(L().digat_gate_bwd(dout.data_ptr(), z.data_ptr(), l.data_ptr(), d, g.data_ptr(), dz.data_ptr(), dl.data_ptr(),
+                                      dg.data_ptr(), B, d, S()), "digat_gate_bwd")
+        return dz, dl, dg
+
+
+class ReluRes(Function):
+    """relu(y) + t   (graphEncoders.py:131)."""
+
+    @staticmethod
+    def forward(ctx, y, t):
+        y, t = _f(y), _f(t)
+        out = torch.empty_like(y)
+        _lib.check(L().digat_relu_res_fwd(y.data_ptr(), t.data_ptr(), out.data_ptr(), y.numel(), S()), "digat_relu_res_fwd")
+        ctx.save_for_backward(y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        dout = _f(dout)
+        dy = torch.empty_like(y)
+        _lib.check(L().digat_relu_mask(dout.data_ptr(), y.data_ptr(), dy.data_ptr(), y.numel(), S()), "digat_relu_mask")
+        return dy, dout
+
+
+class XattnLayer(Function):
+    """Eq. 8 layer on already-dropped-out inputs Xd: out = relu(dropout_p(alpha) @ h) + Xd."""
+
+    @staticmethod
+    def forward(ctx, Xd, A, r, W, bW, F1, F2, a, p_alpha):
+        Xd, r = _f(Xd), _f(r)
+        B, n, d = Xd.shape
+        dev = Xd.device
+        h, Pr, Q = (torch.empty_like(Xd) for _ in range(3))
+        _lib.check(L().digat_xattn_project(Xd.data_ptr(), r.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(), F2.data_ptr(),
+                                           h.data_ptr(), Pr.data_ptr(), Q.data_ptr(), B, n, d, S()), "digat_xattn_project")
+        out = torch.empty_like(Xd)
+        alpha = torch.empty((B, n, n), dtype=torch.float32, device=dev)
+        s_pre = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
+        p = float(p_alpha)
+        adrop = torch.empty_like(alpha) if p > 0 else None
+        amask = torch.empty((B, n, n), dtype=torch.uint8, device=dev) if p > 0 else None
+        _lib.check(L().digat_xattn_pairwise_fwd_train(Pr.data_ptr(), Q.data_ptr(), h.data_ptr(), Xd.data_ptr(), a.data_ptr(),
+                                                      A.data_ptr(), out.data_ptr(), alpha.data_ptr(), s_pre.data_ptr(),
+                                                      _lib.ptr(adrop), _lib.ptr(amask), p, _seed() if p > 0 else 0, B, n, d, S()),
+                   "digat_xattn_pairwise_fwd_train")
+        ctx.save_for_backward(Xd, A, W, F1, F2, a, h, Pr, Q, out, alpha, s_pre, amask if amask is not None else A)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        Xd, A, W, F1, F2, a, h, Pr, Q, out, alpha, s_pre, amask = ctx.saved_tensors
+        B, n, d = Xd.shape
+        dev = Xd.device
+        dOut = _f(dOut)
+        M = B * n
+        dPr, dQ, dh = (torch.empty_like(Xd) for _ in range(3))
+        da = torch.empty_like(a)
+        nb = L().digat_xattn_pairwise_bwd_workspace(B, n, d)
+        ws = _lib.workspace(nb, dev, "xattn_bwd")
+        _lib.check(L().digat_xattn_pairwise_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), Pr.data_ptr(), Q.data_ptr(),
+                                                h.data_ptr(), a.data_ptr(), A.data_ptr(), alpha.data_ptr(), s_pre.data_ptr(),
+                                                amask.data_ptr() if ctx.p > 0 else None, ctx.p, dPr.data_ptr(), dQ.data_ptr(),
+                                                dh.data_ptr(), da.data_ptr(), 0, B, n, d, ws.data_ptr(), nb, S()),
+                   "digat_xattn_pairwise_bwd")
+        # projections: dXd = dOut (residual) + dh W + dP' F1 + dQ F2
+        dXd = dOut.clone()
+        for g_, w_ in ((dh, W), (dPr, F1), (dQ, F2)):
+            _lib.check(L().digat_linear_bwd_input(g_.data_ptr(), d, w_.data_ptr(), dXd.data_ptr(), d, M, d, d, 1, S()),
+                       "digat_linear_bwd_input")
+        dW, dF1, dF2 = torch.empty_like(W), torch.empty_like(F1), torch.empty_like(F2)
+        dbW = torch.empty(d, dtype=torch.float32, device=dev)
+        nbw = L().digat_linear_bwd_weight_workspace(M, d, d)
+        wsw = _lib.workspace(nbw, dev, "dW")
+        for g_, dw_, db_ in ((dh, dW, dbW), (dPr, dF1, None), (dQ, dF2, None)):
+            _lib.check(L().digat_linear_bwd_weight(g_.data_ptr(), d, Xd.data_ptr(), d, dw_.data_ptr(), _lib.ptr(db_), M, d, d, 0,
+                                                   wsw.data_ptr(), nbw, S()), "digat_linear_bwd_weight")
+        dr = torch.empty((B, d), dtype=torch.float32, device=dev)
+        _lib.check(L().digat_sum_nodes(dPr.data_ptr(), dr.data_ptr(), B, n, d, S()), "digat_sum_nodes")
+        return dXd, None, dr, dW, dbW, dF1, dF2, da.view_as(a), None
+
+
+# --------------------------------------------------------------------------------------------------
+# the reference's four functions, training mode
+# --------------------------------------------------------------------------------------------------
+def news_graph_context(enc, X, mask_bytes, p, training=True):
+    ca = enc.candidate_attention
+    local = X[:, 0]                                                   # select: a strided view, no copy
+    qv = Linear.apply(local, ca.Q.weight, ca.Q.bias)
+    kq = MatmulW.apply(qv, ca.K.weight)
+    glob = AttnPool.apply(X, kq, mask_bytes)
+    z = Linear.apply(torch.cat([local, glob], dim=1), enc.news_graph_W.weight, enc.news_graph_W.bias)
+    z = dropout(z, p / 2, training)
+    return GateMix.apply(z, local, glob)
+
+
+def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True):
+    H, C1 = enc.max_history_num, enc.category_num
+    d = Xu.shape[2]
+    qv = Linear.apply(c_n, enc.user_news_Q.weight, enc.user_news_Q.bias)
+    kq = MatmulW.apply(qv, enc.user_news_K.weight)
+    T = TopicPool.apply(Xu, kq, cat_idx, H, C1)
+    y = Linear.apply(T.view(-1, d), enc.featureAffine.weight, enc.featureAffine.bias).view_as(T)
+    T2 = dropout(ReluRes.apply(y, T), p, training)
+    ua = enc.userAttention
+    qv2 = Linear.apply(c_n, ua.Q.weight, ua.Q.bias)
+    kq2 = MatmulW.apply(qv2, ua.K.weight)
+    return AttnPool.apply(T2, kq2, cat_mask_bytes)
+
+
+def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True):
+    Xd = dropout(X, p / 2, training)
+    F3 = getattr(enc, f"{g}_graph_attention_ffn3")[i]
+    W = getattr(enc, f"{g}_graph_attention_W")[i]
+    r = Linear.apply(ctx_vec, F3.weight, F3.bias)
+    return XattnLayer.apply(Xd, A_bytes, r, W.weight, W.bias,
+                            getattr(enc, f"{g}_graph_attention_ffn1")[i].weight,
+                            getattr(enc, f"{g}_graph_attention_ffn2")[i].weight,
+                            getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0)
+
+
+def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                        user_category_mask, user_category_indices):
+    """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24)."""
+    p = enc.dropout_rate
+    Xn = _lib.f32(news_graph_embeddings)
+    ue = _lib.f32(user_news_embedding)
+    _lib.require_device(Xn, news_graph, news_graph_mask, ue, user_graph, user_category_mask, user_category_indices)
+    An, Mn = _lib.as_bytes(news_graph), _lib.as_bytes(news_graph_mask)
+    Au, cm = _lib.as_bytes(user_graph), _lib.as_bytes(user_category_mask)
+    ci = user_category_indices.to(torch.int64).contiguous()
+    B = Xn.shape[0]
+    topic = dropout(enc.topic_node_embedding.unsqueeze(0).expand(B, -1, -1), p / 2)
+    Xu = torch.cat([ue, topic], dim=1)
+    c_n = news_graph_context(enc, Xn, Mn, p)
+    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p)
+    for i in range(enc.graph_depth):
+        Xn_next = graph_embeddings(enc, "news", i, Xn, An, c_u, p)
+        Xu_next = graph_embeddings(enc, "user", i, Xu, Au, c_n, p)
+        Xn, Xu = Xn_next, Xu_next
+        c_n = c_n + news_graph_context(enc, Xn, Mn, p)
+        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p)
+    return c_n, c_u

@@ -165,6 +165,48 @@ int digat_encoder_fwd(const digat_params* params,
 /* H1: Model.inference's last line (model.py:89): logits[b] = sum_c user_ctx[b,c] * news_ctx[b,c]. */
 int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream);
 
+/* ---- training: native forward/backward pairs for every op on the path ----------------------------
+ * The reference trains by autograd through DIGAT.forward (trainer.py:98-102).  digat_amd/training.py
+ * composes the same forward from these primitives (each an autograd.Function); Eq. 8's backward
+ * recomputes relu'(K3+K1+K2) from the saved projections instead of saving [B,n,n,d].  All reductions
+ * are ordered (no atomics), so gradients are run-to-run reproducible.  `accumulate` != 0 adds into the
+ * destination. */
+int digat_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
+                           int M, int N, int K, int accumulate, void* stream);           /* dx[M,K] = dy[M,N] @ w[N,K] */
+size_t digat_linear_bwd_weight_workspace(int M, int No, int Ni);
+int digat_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db,
+                            int M, int No, int Ni, int accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream);                                                /* dW = dy^T x, db = colsum(dy) */
+int digat_colsum(const float* x, int64_t ldx, float* out, int M, int N, int accumulate, void* stream);
+int digat_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint32_t seed, void* stream);
+int digat_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+int digat_gate_fwd(const float* z, const float* l, int64_t ldl, const float* g, float* out, int B, int d, void* stream);
+int digat_gate_bwd(const float* dout, const float* z, const float* l, int64_t ldl, const float* g,
+                   float* dz, float* dl, float* dg, int B, int d, void* stream);
+int digat_relu_res_fwd(const float* y, const float* t, float* out, int64_t n, void* stream);   /* relu(y) + t */
+int digat_relu_mask(const float* dout, const float* y, float* dy, int64_t n, void* stream);    /* dout * [y > 0] */
+int digat_attn_pool_fwd(const float* feat, int64_t ld_b, const float* kq, const uint8_t* mask, float* out,
+                        float* alpha_out, int B, int n, int d, void* stream);
+int digat_attn_pool_bwd(const float* feat, int64_t ld_b, const float* kq, const uint8_t* mask, const float* alpha,
+                        const float* dout, float* dfeat, int64_t ldd_b, float* dkq, int B, int n, int d,
+                        int accumulate_dfeat, void* stream);
+int digat_topic_pool_fwd_train(const float* Xu, const float* kq, const int64_t* cat_idx, float* out, float* alpha_out,
+                               int B, int U, int H, int C1, int d, void* stream);
+int digat_topic_pool_bwd(const float* Xu, const float* kq, const int64_t* cat_idx, const float* alpha, const float* dT,
+                         float* dXu, float* dkq, int B, int U, int H, int C1, int d, void* stream);
+int digat_xattn_project(const float* X, const float* r, const float* W, const float* bW, const float* F1,
+                        const float* F2, float* h, float* Pr, float* Q, int B, int n, int d, void* stream);
+int digat_xattn_pairwise_fwd_train(const float* Pr, const float* Q, const float* h, const float* X, const float* a,
+                                   const uint8_t* A, float* out, float* alpha, float* s_pre, float* alpha_drop,
+                                   uint8_t* amask, float p, uint32_t seed, int B, int n, int d, void* stream);
+size_t digat_xattn_pairwise_bwd_workspace(int B, int n, int d);
+int digat_xattn_pairwise_bwd(const float* dOut, const float* out, const float* Xres, const float* Pr, const float* Q,
+                             const float* h, const float* a, const uint8_t* A, const float* alpha, const float* s_pre,
+                             const uint8_t* amask, float p, float* dPr, float* dQ, float* dh, float* da,
+                             int accumulate_da, int B, int n, int d, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* stream);          /* dr[b] = sum_j dP[b,j] */
+
 /* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
  * Between start and stop every kernel launch of this library is bracketed by two events recorded
  * on the stream it is launched on.  stop() synchronises and returns, per kernel kind, the summed

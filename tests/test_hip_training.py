@@ -1,0 +1,110 @@
+"""GPU suite: training-mode forward/backward through the HIP primitives (digat_amd/training.py) against
+the loss and gradients the REFERENCE's autograd produced for one step (tests/golden/train_step.npz,
+dropout 0 so that train mode is deterministic; trainer.py:98-102, model.py:54-77).
+
+Tolerance: gradients are long fp32 sums (over B*n rows, n*n pairs, d channels) evaluated in a different
+order than ATen's -> 2e-4 relative + 2e-6 absolute on each gradient tensor.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(got, want, what, rtol=2e-4, atol=2e-6):
+    got = got.detach().cpu().numpy()
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite"
+    scale = max(float(np.abs(want).max()), 1e-12)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.maximum(np.abs(want), 0.05 * scale)
+    if (err > tol).any():
+        idx = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: max|diff|={err.max():.3e} (scale {scale:.3e}) at {idx}: got {got[idx]:.7g} want {want[idx]:.7g}")
+
+
+def build(fx, dropout):
+    from digat_amd.graphEncoders import DIGAT
+    B, K, N, H, C, d, L = (int(v) for v in fx["meta"])
+    ins, w, outs = split_fixture(fx)
+    cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C, graph_depth=L, dropout_rate=dropout)
+    enc = DIGAT(cfg, d)
+    enc.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()})
+    enc = enc.to(DEV).train()
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in ins.items()}
+    return enc, t, outs, (B, K, N, H, C, d, L)
+
+
+def run_step(enc, t, dims):
+    B, K, N, H, C, d, L = dims
+    Xn = t["news_graph_embeddings"].clone().requires_grad_(True)
+    ue = t["user_news_embedding"].clone().requires_grad_(True)
+
+    def expand(x):                                                   # model.py:64-71
+        return x.unsqueeze(1).expand(B, K, *x.shape[1:]).contiguous().view(B * K, *x.shape[1:])
+
+    n, u = enc(Xn, t["news_graph"], t["news_graph_mask"], expand(ue), expand(t["user_graph"]),
+               expand(t["user_category_mask"]), expand(t["user_category_indices"]))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()    # trainer.py:100
+    loss.backward()
+    return logits, loss, Xn, ue
+
+
+def test_training_step_matches_reference_autograd():
+    fx = load_golden("train_step.npz")
+    enc, t, outs, dims = build(fx, dropout=0.0)
+    logits, loss, Xn, ue = run_step(enc, t, dims)
+    torch.cuda.synchronize()
+    close(logits, outs["logits"], "logits", rtol=1e-5, atol=1e-5)
+    close(loss, outs["loss"], "loss", rtol=1e-5, atol=1e-6)
+    close(Xn.grad, fx["g_in_news_graph_embeddings"], "d news_graph_embeddings")
+    close(ue.grad, fx["g_in_user_news_embedding"], "d user_news_embedding")
+    for name, p in enc.named_parameters():
+        assert p.grad is not None, name
+        close(p.grad, fx["g_" + name], "grad " + name)
+
+
+def test_training_gradients_are_reproducible():
+    fx = load_golden("train_step.npz")
+    grads = []
+    for _ in range(2):
+        enc, t, outs, dims = build(fx, dropout=0.0)
+        run_step(enc, t, dims)
+        grads.append({n: p.grad.clone() for n, p in enc.named_parameters()})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n            # ordered reductions: bit-identical
+
+
+def test_dropout_kernel_statistics_and_train_mode_runs():
+    from digat_amd import training
+    x = torch.ones(1 << 20, device=DEV)
+    y = training.Dropout.apply(x, 0.2)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.8) < 5e-3
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1.25))
+    y2 = training.Dropout.apply(x, 0.2)
+    assert not torch.equal(y, y2)                                   # fresh seed per call
+    fx = load_golden("train_step.npz")
+    enc, t, outs, dims = build(fx, dropout=0.2)
+    logits, loss, Xn, ue = run_step(enc, t, dims)
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in enc.parameters())
+    # eval mode of the same module is untouched by the training path
+    enc.eval()
+    with torch.no_grad():
+        B, K = dims[0], dims[1]
+
+        def expand(x):
+            return x.unsqueeze(1).expand(B, K, *x.shape[1:]).contiguous().view(B * K, *x.shape[1:])
+        n, u = enc(t["news_graph_embeddings"], t["news_graph"], t["news_graph_mask"], expand(t["user_news_embedding"]),
+                   expand(t["user_graph"]), expand(t["user_category_mask"]), expand(t["user_category_indices"]))
+    d = dims[5]
+    lg = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    close(lg, outs["logits"], "eval logits after training", rtol=1e-5, atol=1e-5)
