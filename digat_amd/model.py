@@ -29,7 +29,7 @@ class Model(nn.Module):
         else:
             raise Exception(config.graph_encoder + ' is not implemented')
         self.model_name = str(getattr(config, 'news_encoder', 'MSA')) + '-' + config.graph_encoder
-        self.max_title_length = getattr(config, 'max_title_length', 32)
+        self.max_title_length = getattr(config, 'max_title_length', 32) if news_encoder is None else getattr(config, 'max_title_length', 1)
         self.max_history_num = config.max_history_num
         self.category_num = config.category_num + 1
         self.news_embedding_dim = self.news_encoder.news_embedding_dim
@@ -82,13 +82,24 @@ class Model(nn.Module):
 
 
 class PrecomputedNewsEncoder(nn.Module):
-    """Stand-in producer for synthetic runs: news id -> fixed embedding row (no title text exists).
-    Takes ids shaped [B, n] (the mask argument is ignored) and returns [B, n, d]."""
+    """Stand-in producer for synthetic runs: news id -> embedding row (no title text exists).
+    Takes ids shaped [B, n] or [B, n, 1] (a "title" of one token = the news id; the mask argument is ignored)
+    and returns [B, n, d].  ``trainable=True`` makes the table a parameter (named ``embed_table`` so that the
+    trainer's 'embed' no-decay rule applies, trainer.py:25)."""
 
-    def __init__(self, table: torch.Tensor):
+    def __init__(self, table: torch.Tensor, trainable: bool = False):
         super().__init__()
-        self.register_buffer("table", table)
+        if trainable:
+            self.embed_table = nn.Parameter(table.clone())
+        else:
+            self.register_buffer("embed_table", table)
         self.news_embedding_dim = int(table.shape[1])
 
+    @property
+    def table(self):
+        return self.embed_table
+
     def forward(self, news_ids, _mask=None):
-        return self.table[news_ids.long()]
+        if news_ids.dim() == 3 and news_ids.shape[2] == 1:
+            news_ids = news_ids.squeeze(2)
+        return self.embed_table[news_ids.long()]

@@ -1,0 +1,163 @@
+"""Training harness: the counterpart of the reference's ``trainer.py`` for the path this repo owns.
+
+Same step as trainer.py:71-105 — Adam(lr) with the ``['.bias', 'embed', 'graph_encoder.']`` no-decay
+split (:25-30), loss = mean(-log_softmax(logits)[:, 0]) (:100), clip_grad_norm_ (:103-104), lr / 10 at
+epoch ``E - ((E-1)//10 + 1) + 1`` (:32, :81-82), DistributedDataParallel + DistributedSampler when
+launched with one process per GPU (:19, :78-80; backend "nccl" is RCCL on ROCm) — around
+``Model.forward``, whose graph encoder runs on the HIP kernels forward and backward.
+
+Real MIND is not reachable from this environment, so the data side is ``SyntheticTrainSet``: behaviours
+with one clicked and ``negative_sample_num`` sampled non-clicked candidates (MIND_dataset.py:26-47),
+indexed into the device-resident synthetic corpus (no DataLoader workers: a batch is a few index_selects).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import util
+from .evaluate import AvgMetric
+
+
+def training_loss(logits: torch.Tensor) -> torch.Tensor:
+    """trainer.py:100 — the clicked candidate is column 0."""
+    return (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+
+
+def lr_decay_epoch(epochs: int) -> int:
+    """First epoch that runs at lr/10 (trainer.py:32,81): E - ((E-1)//10 + 1) + 1."""
+    return epochs - ((epochs - 1) // 10 + 1) + 1
+
+
+def parameter_groups(model: nn.Module, weight_decay: float):
+    no_decay = ['.bias', 'embed', 'graph_encoder.']                     # trainer.py:25
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    return [
+        {'params': [p for n, p in named if not any(nd in n.lower() for nd in no_decay)], 'weight_decay': weight_decay},
+        {'params': [p for n, p in named if any(nd in n.lower() for nd in no_decay)], 'weight_decay': 0.0},
+    ]
+
+
+class SyntheticTrainSet:
+    """Training behaviours on a synthetic corpus: (impression, clicked news, non-clicked pool)."""
+
+    def __init__(self, corpus, negative_sample_num: int = 4, seed: int = 0):
+        self.neg = negative_sample_num
+        self.rng = np.random.default_rng(seed)
+        imp, cand, lab = corpus.row_impression, corpus.row_candidate, corpus.row_label
+        bounds = np.r_[0, np.flatnonzero(np.diff(imp)) + 1, len(imp)]
+        self.behaviors = []                                              # (impression, clicked, [non-clicked])
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            pos, negs = cand[s:e][lab[s:e] == 1], cand[s:e][lab[s:e] == 0]
+            if len(negs) == 0:
+                continue
+            for c in pos:
+                self.behaviors.append((int(imp[s]), int(c), negs))
+        self.samples = np.zeros((len(self.behaviors), 1 + self.neg), dtype=np.int64)
+        self.impression = np.array([b[0] for b in self.behaviors], dtype=np.int64)
+
+    def negative_sampling(self):
+        """MIND_dataset.py:26-47: without replacement when the pool is large enough, cyclic otherwise."""
+        for i, (_, click, negs) in enumerate(self.behaviors):
+            self.samples[i, 0] = click
+            if len(negs) <= self.neg:
+                self.samples[i, 1:] = negs[np.arange(self.neg) % len(negs)]
+            else:
+                self.samples[i, 1:] = self.rng.choice(negs, size=self.neg, replace=False)
+
+    def __len__(self):
+        return len(self.behaviors)
+
+
+class Trainer:
+    def __init__(self, model: nn.Module, config, dc: "util.DeviceCorpus", train_set: SyntheticTrainSet,
+                 local_rank: int = -1):
+        self.local_rank = local_rank
+        self.is_main_rank = local_rank in (-1, 0)
+        if local_rank == -1:
+            self.model = model
+        else:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            self.model = DDP(model, device_ids=[local_rank], output_device=local_rank)
+        self.epochs = config.epoch
+        self.batch_size = config.batch_size
+        self.optimizer = optim.Adam(parameter_groups(self.model, getattr(config, "weight_decay", 0.0)), lr=config.lr)
+        self.gradient_clip_norm = getattr(config, "gradient_clip_norm", 1.0)
+        self.decay_epoch = lr_decay_epoch(self.epochs)
+        self.dc, self.train_set = dc, train_set
+        self.losses = []
+
+    def lr_decay(self):
+        for group in self.optimizer.param_groups:
+            group['lr'] = group['lr'] / 10
+
+    def batches(self, epoch: int):
+        n = len(self.train_set)
+        order = np.random.default_rng(1000 + epoch).permutation(n)
+        if self.local_rank != -1:                                        # DistributedSampler: strided shards
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(), dist.get_rank()
+            total = (n + world - 1) // world * world
+            order = np.r_[order, order[: total - n]][rank::world]
+        for s in range(0, len(order), self.batch_size):
+            yield order[s:s + self.batch_size]
+
+    def gather(self, idx: np.ndarray):
+        """The 9 inputs of Model.forward (trainer.py:88-96) for the behaviours ``idx`` — news ids stand in for
+        title text (the synthetic news 'encoder' is an embedding table)."""
+        dc, dev = self.dc, self.dc.news_embedding.device
+        imp = torch.from_numpy(self.train_set.impression[idx]).to(dev)
+        news = torch.from_numpy(self.train_set.samples[idx]).to(dev)               # [B, 1+neg]
+        B, K = news.shape
+        node_ids = dc.news_node_ID.index_select(0, news.flatten()).view(B, K, -1, 1)  # [B,K,N,1]
+        hist = dc.history.index_select(0, imp).unsqueeze(2)                        # [B,H,1]
+        return (hist, torch.ones_like(hist, dtype=torch.bool), dc.user_graph.index_select(0, imp),
+                dc.user_category_mask.index_select(0, imp), dc.user_category_indices.index_select(0, imp),
+                node_ids, torch.ones_like(node_ids, dtype=torch.bool),
+                dc.news_graph.index_select(0, news.flatten()).view(B, K, *dc.news_graph.shape[1:]),
+                dc.news_graph_mask.index_select(0, news.flatten()).view(B, K, -1))
+
+    def train_step(self, idx: np.ndarray) -> float:
+        logits = self.model(*self.gather(idx))                          # [B, 1+neg]
+        loss = training_loss(logits)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.gradient_clip_norm > 0:
+            nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip_norm)
+        self.optimizer.step()
+        return float(loss.item())
+
+    def train(self, max_steps: Optional[int] = None, log_every: int = 0):
+        step = 0
+        for e in range(1, self.epochs + 1):
+            self.train_set.negative_sampling()
+            if e == self.decay_epoch:
+                self.lr_decay()
+            self.model.train()
+            epoch_loss, nb = 0.0, 0
+            for idx in self.batches(e):
+                loss = self.train_step(idx)
+                epoch_loss += loss
+                nb += 1
+                step += 1
+                if log_every and self.is_main_rank and step % log_every == 0:
+                    print(f"epoch {e} step {step} loss {loss:.4f}", flush=True)
+                if max_steps is not None and step >= max_steps:
+                    self.losses.append(epoch_loss / max(nb, 1))
+                    return self.losses
+            self.losses.append(epoch_loss / max(nb, 1))
+            if self.is_main_rank:
+                print(f"Epoch {e} : train done\nloss = {self.losses[-1]}", flush=True)
+        return self.losses
+
+
+def evaluate_dev(model, dc, labels, batch_size: int):
+    """Per-epoch dev evaluation (trainer.py:109-120): AUC / MRR / nDCG through the HIP inference path."""
+    net = model.module if hasattr(model, "module") else model
+    scores, metrics = util.compute_scores(net, dc, batch_size, labels=labels)
+    return AvgMetric(*metrics)

@@ -1,0 +1,44 @@
+"""CPU suite for the trainer's host logic (no kernels): lr schedule, parameter groups, negative sampling,
+loss — against the reference's rules (trainer.py:25-32,81,100; MIND_dataset.py:26-47)."""
+import types
+
+import numpy as np
+import torch
+
+from digat_amd import synthetic
+from digat_amd.trainer import SyntheticTrainSet, lr_decay_epoch, parameter_groups, training_loss
+
+
+def test_lr_decay_epoch_matches_reference_rule():
+    # trainer.py:32,81: decay when e == epoch - ((epoch-1)//10 + 1) + 1
+    assert lr_decay_epoch(16) == 15          # MIND-small: 16 epochs -> lr/10 from epoch 15
+    assert lr_decay_epoch(7) == 7            # MIND-large: 7 epochs -> last epoch
+    assert lr_decay_epoch(1) == 1
+
+
+def test_parameter_groups_follow_the_no_decay_rule():
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=4, max_history_num=10,
+                                category_num=5, graph_depth=1, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.zeros(16, 64), trainable=True))
+    decay, no_decay = parameter_groups(model, 0.01)
+    assert decay["params"] == []                               # everything here is graph_encoder.* or an embedding
+    assert len(no_decay["params"]) == len(list(model.parameters()))
+    assert no_decay["weight_decay"] == 0.0 and decay["weight_decay"] == 0.01
+
+
+def test_negative_sampling_and_loss():
+    spec = synthetic.SynthSpec(news_num=256, sag_neighbors=3, sag_hops=1, max_history_num=10, category_num=5,
+                               embedding_dim=16, impressions=40, mean_candidates=8.0, max_candidates=20, seed=3)
+    corpus = synthetic.make_corpus(spec)
+    ts = SyntheticTrainSet(corpus, negative_sample_num=4, seed=0)
+    ts.negative_sampling()
+    assert 0 < len(ts) <= int((corpus.row_label == 1).sum())       # one behaviour per clicked candidate
+    for i, (imp, click, negs) in enumerate(ts.behaviors):
+        assert ts.samples[i, 0] == click
+        assert set(ts.samples[i, 1:].tolist()) <= set(negs.tolist())
+        if len(set(negs.tolist())) == len(negs) > 4:
+            assert len(set(ts.samples[i, 1:].tolist())) == 4       # positions drawn without replacement
+    logits = torch.tensor([[2.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    want = (-torch.log_softmax(logits, dim=1)[:, 0]).mean()
+    assert torch.allclose(training_loss(logits), want)
