@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--news", type=int, default=8192, help="synthetic news corpus size per rank")
     ap.add_argument("--cpu-rows", type=int, default=1536, help="max rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
+    ap.add_argument("--per-row-users", action="store_true",
+                    help="expand the user tensors per row as the reference's driver does (default: once per impression)")
     ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "fp32"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA")
     return ap.parse_args()
@@ -114,12 +116,16 @@ def main():
     mean_cand = corpus.rows / float(spec.impressions)
 
     scores_buf = torch.empty(B, dtype=torch.float32, device=dev)
+    imp_host = corpus.row_impression
 
     def step(i):
         s = (i % nbatches) * B
         e = min(s + B, dc.rows)
         with torch.no_grad():
-            scores_buf[:e - s] = model.inference(*util.gather_batch(dc, s, e))
+            if args.per_row_users:
+                scores_buf[:e - s] = model.inference(*util.gather_batch(dc, s, e))
+            else:
+                scores_buf[:e - s] = model.inference_grouped(*util.gather_batch_grouped(dc, s, e, imp_host))
         return e - s
 
     def fence():
@@ -279,7 +285,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl["label"], "projection": args.projection, "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
+        "config": {"workload": wl["label"], "projection": args.projection,
+                   "user_side": "per row" if args.per_row_users else "once per impression (row_group index)", "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
                    "mean_candidates_per_impression": round(mean_cand, 3), "parallelism": f"dp{world} (row shards, no data-path collective)"},
         "rows_per_s": rows_total / elapsed,
         "roofline": roof(dom),

@@ -32,7 +32,7 @@ class Params(C.Structure):
                                      "userAtt_K", "userAtt_Q", "userAtt_bQ")]
                 + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)]
                 + [(k, _f) for k in ("cand_fold_W", "cand_fold_b", "user_news_fold_W", "user_news_fold_b",
-                                     "userAtt_fold_W", "userAtt_fold_b")])
+                                     "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit")])
 
 
 class DigatHipError(RuntimeError):
@@ -56,8 +56,11 @@ _SIGNATURES = {
     "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
+    "digat_encoder_grouped_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_encoder_fwd_grouped": (C.c_int, [C.POINTER(Params)] + [_f] * 11 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "digat_split_proj_weights": (C.c_int, [_f, _f, _f, C.c_int, _f, _f]),
+    "digat_split_weights": (C.c_int, [_f, C.c_int, C.c_int, _f, _f]),
     "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f]),
     "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
     "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),

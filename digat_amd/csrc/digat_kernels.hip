@@ -83,6 +83,7 @@ struct GemmArgs {
     int mtiles, ntiles;
     const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
     const float* radd; int radd_seg, rows_per_b;   // segment radd_seg: y += radd[row / rows_per_b][col]  (K3 + K1 of Eq. 8)
+    int m_dispatch;                                // != 0: choose the kernel as if M were this (bit-identical results across batchings)
 };
 
 // LDS image: float4 tile[k4][row ^ k4]  (k4 = 4-float column group of the 32-deep K tile).
@@ -485,6 +486,7 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
                 if (gm >= g.M) continue;
                 float v = acc[mt][nt][r] + bv;
                 if (radd) v = radd[rrow[mt][r] + nn] + v;
+                if (g.epi == EPI_RELU_RES) v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
                 yp[(long)gm * g.ldy + nn] = v;
             }
         }
@@ -610,7 +612,8 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
-    if (g.M < 2048 && g.nseg % 80 == 0 && !g.transW && g.K % 4 == 0 && g.k0 % 16 == 0 && !g.radd) {
+    const int Md = g.m_dispatch > 0 ? g.m_dispatch : g.M;
+    if (Md < 2048 && g.nseg % 80 == 0 && !g.transW && g.K % 4 == 0 && g.k0 % 16 == 0 && !g.radd) {
         ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
         g.mtiles = (g.M + 31) / 32;
         g.ntiles = Ntot / 80;
@@ -621,7 +624,7 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
     // tile configuration: 128x80 for the big projections; below 2048 rows 32x64 (most workgroups), or
     // 64x80 for multi-segment launches whose segments are multiples of 80 columns (d = 400); the small-M
     // shapes keep two K tiles in flight
-    const int cfg = g.M >= 2048 ? 0 : ((g.nsegs > 1 && g.nseg % 80 == 0) ? 1 : 2);
+    const int cfg = Md >= 2048 ? 0 : ((g.nsegs > 1 && g.nseg % 80 == 0) ? 1 : 2);
     const int bn = cfg == 2 ? 64 : 80;
     if (g.nsegs > 1 && g.nseg % bn != 0) {
         // a tile must lie inside one weight segment; when the tile width does not divide the segment
@@ -636,7 +639,8 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         return DIGAT_OK;
     }
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
-    if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.epi == EPI_NONE && g.k0 == g.K && !g.transW) {
+    if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
+        g.k0 == g.K && !g.transW) {
         g.mtiles = (g.M + 127) / 128;
         g.ntiles = (Ntot + 79) / 80;
         hipLaunchKernelGGL((gemm_bf16x6_kernel<128, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
@@ -1309,15 +1313,42 @@ static int launch_topic(const float* Xu, long ld_b, const float* kq, const int64
 // 5. glue kernels
 // =================================================================================================
 // Xu[b] = [user_news_embedding[b] (H rows) | topic_node_embedding (C rows)]   (graphEncoders.py:191)
+// group != NULL: row b takes the history of user group[b] (rows of one impression share the user side)
 __global__ void __launch_bounds__(256) build_user_nodes_kernel(const float4* ue, const float4* topic, float4* Xu,
-                                                               long B, int H, int C, int d4) {
+                                                               long B, int H, int C, int d4, const int* group) {
     const long per_row = (long)(H + C) * d4;
     const long total = B * per_row;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long b = i / per_row;
         const long rem = i - b * per_row;
         const long hist = (long)H * d4;
-        Xu[i] = rem < hist ? ue[b * hist + rem] : topic[rem - hist];
+        const long src = group ? group[b] : b;
+        Xu[i] = rem < hist ? ue[src * hist + rem] : topic[rem - hist];
+    }
+}
+
+// out[b] = in[group[b]] for rows of `row_bytes` bytes (16-byte multiple or byte-wise)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const uint8_t* in, uint8_t* out, const int* group, long B, long row_bytes) {
+    const long total = B * row_bytes;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / row_bytes;
+        out[i] = in[(long)group[b] * row_bytes + (i - b * row_bytes)];
+    }
+}
+
+// layer-0 user graph of grouped rows: h[b] = h0[g], P'[b] = r[b] + P0[g] (K3 + K1), Q[b] = Q0[g]
+__global__ void __launch_bounds__(256) expand_proj_kernel(const float4* h0, const float4* P0, const float4* Q0, const float4* r,
+                                                          const int* group, float4* h, float4* Pr, float4* Q, long B, int n, int d4) {
+    const long per_row = (long)n * d4;
+    const long total = B * per_row;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / per_row;
+        const long rem = i - b * per_row;
+        const long src = (long)group[b] * per_row + rem;
+        const int c4 = (int)(rem % d4);
+        h[i] = h0[src];
+        Q[i] = Q0[src];
+        Pr[i] = f4_add(r[b * d4 + c4], P0[src]);
     }
 }
 
@@ -1420,6 +1451,17 @@ int digat_split_proj_weights(const float* W, const float* F1, const float* F2, i
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, F1, F2, d, 3, d,
+                       (unsigned short*)wsplit);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream) {
+    if (!W || !wsplit || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
+    const long total = (long)N * K;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, W, W, N, 1, K,
                        (unsigned short*)wsplit);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
@@ -1569,7 +1611,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* cws, float* kq_t, float* kq_u, float* r_user, float* r_news,
-                              hipStream_t st) {
+                              hipStream_t st, const int* row_group, int G, const float* ue_groups) {
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
@@ -1592,6 +1634,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
+        g.wsplit = (const unsigned short*)p->featureAffine_wsplit;       // non-NULL: bf16x6
         e = launch_gemm(g, st);
         if (e) return e;
         return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, st);
@@ -1622,7 +1665,51 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit);
         if (rc) return rc;
-        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
+        if (i == 0 && row_group) {
+            // layer 0 of grouped rows: every row of a group has the same user nodes, so project the G groups
+            // once ([G*U] rows instead of [B*U]) and expand h | P' = r + P | Q per row
+            const size_t ndg = (size_t)G * U * d;
+            float* Xg = Xu[1];                                  // free until this layer's output is written
+            float* h0 = Xg + ndg;                               // G << B: all four fit in the [B,U,d] buffer
+            float* P0 = h0 + ndg;
+            float* Q0 = P0 + ndg;
+            {
+                const long total4 = (long)ndg / 4;
+                int blocks = (int)((total4 + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue_groups,
+                                   (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
+                DIGAT_CHECK_LAUNCH();
+            }
+            GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
+            gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
+            gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = Q0;
+            gg.nsegs = 3;
+            gg.wsplit = (const unsigned short*)lu.wsplit;
+            gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
+            rc = launch_gemm(gg, st, DIGAT_KERNEL_PROJ);
+            if (rc) return rc;
+            const size_t nd = (size_t)B * U * d;
+            float* h = (float*)xws;
+            float* P = h + nd;
+            float* Q = P + nd;
+            float* alpha = (float*)((char*)xws + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
+            {
+                const long total4 = (long)nd / 4;
+                int blocks = (int)((total4 + 255) / 256);
+                if (blocks > 4096) blocks = 4096;
+                ProfScope prof(DIGAT_KERNEL_GLUE, (double)nd * 4 * 3, st);
+                hipLaunchKernelGGL(expand_proj_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)h0, (const float4*)P0,
+                                   (const float4*)Q0, (const float4*)r_user, row_group, (float4*)h, (float4*)P, (float4*)Q,
+                                   (long)B, U, d / 4);
+                DIGAT_CHECK_LAUNCH();
+            }
+            // Xu[1] is about to be overwritten by the layer output while h0/P0/Q0 live there: they are consumed
+            // (expanded) before the pairwise kernels run, and the output is written only by the aggregation
+            rc = launch_xattn_pairwise(P, Q, h, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st);
+        } else {
+            rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
+        }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
         rc = news_ctx(xn_cur);                     // c_n += ... (:196)
@@ -1648,10 +1735,13 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     return tot;
 }
 
-int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
-                      const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
-                      const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+// row_group == NULL: user tensors are per row.  Otherwise they are per group (G of them) and row_group[b]
+// names the group of row b; the caller (digat_encoder_fwd_grouped) has expanded the small per-row byte /
+// index arrays, so Au / cat_mask / cat_idx are per row in both cases and only ue [G,H,d] is per group.
+static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                            const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
+                            const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
+                            void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -1689,7 +1779,7 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
         if (blocks > 2048) blocks = 2048;
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)H * d * 8 + (double)C * d * 4), st);
         hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue,
-                           (const float4*)p->topic_node_embedding, (float4*)Xu[0], (long)B, H, C, d / 4);
+                           (const float4*)p->topic_node_embedding, (float4*)Xu[0], (long)B, H, C, d / 4, row_group);
         DIGAT_CHECK_LAUNCH();
     }
     // c_n: given (inference, :189) or computed (forward, :180); it lives in out_news from here on
@@ -1703,7 +1793,7 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
     }
     if (p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  cws, kq_t, kq_u, r_user, r_news, st);
+                                  cws, kq_t, kq_u, r_user, r_news, st, row_group, G, ue);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -1735,6 +1825,49 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
         if (rc) return rc;
     }
     return DIGAT_OK;
+}
+
+int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                      const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
+                      const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(p, Xn_in, An, Mn, ue, Au, cat_mask, cat_idx, c_n0, out_news, out_user, B, N, H, workspace,
+                            workspace_bytes, stream, nullptr, 0);
+}
+
+size_t digat_encoder_grouped_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
+    const int U = H + C;
+    return digat_encoder_workspace_bytes(B, N, H, C, d, depth) + align_up((size_t)B * U * U, 256)
+           + align_up((size_t)B * (C + 1), 256) + align_up((size_t)B * H * 8, 256);
+}
+
+int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                              const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
+                              const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
+                              int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !ue_g || !Au_g || !cat_mask_g || !cat_idx_g || !row_group || !workspace || G <= 0) return DIGAT_ERR_ARG;
+    const int d = p->d, C = p->category_num, U = H + C;
+    if (!p->cand_fold_W || !p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;   // grouped = folded path
+    if ((size_t)4 * G > (size_t)B) return DIGAT_ERR_SHAPE;       // the group-level projections reuse one [B,U,d] buffer
+    if (workspace_bytes < digat_encoder_grouped_workspace_bytes(B, N, H, C, d, p->depth)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // expand the small per-user byte / index arrays to rows (4.6 MB for 1024 rows of 67x67 adjacency)
+    const size_t base = digat_encoder_workspace_bytes(B, N, H, C, d, p->depth);
+    uint8_t* Au = (uint8_t*)workspace + base;
+    uint8_t* cm = Au + align_up((size_t)B * U * U, 256);
+    uint8_t* ci = cm + align_up((size_t)B * (C + 1), 256);
+    struct { const uint8_t* in; uint8_t* out; long bytes; } jobs[3] = {
+        {Au_g, Au, (long)U * U}, {cat_mask_g, cm, (long)(C + 1)}, {(const uint8_t*)cat_idx_g, ci, (long)H * 8}};
+    for (auto& j : jobs) {
+        const long total = (long)B * j.bytes;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, j.in, j.out, row_group, (long)B, j.bytes);
+        DIGAT_CHECK_LAUNCH();
+    }
+    return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
+                            base, stream, row_group, G);
 }
 
 int digat_profile_start(int max_launches) {

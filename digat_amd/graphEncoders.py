@@ -154,6 +154,11 @@ class DIGAT(GraphEncoder):
                         _lib.stream_ptr()), "digat_split_proj_weights")
                     arr[i].wsplit = buf.data_ptr()
                     P._splits.append(buf)
+            buf = torch.empty(L_.digat_split_weights_bytes(d, d), dtype=torch.uint8, device=self.topic_node_embedding.device)
+            _lib.check(L_.digat_split_weights(self.featureAffine.weight.data_ptr(), d, d, buf.data_ptr(), _lib.stream_ptr()),
+                       "digat_split_weights")
+            P.featureAffine_wsplit = buf.data_ptr()
+            P._splits.append(buf)
         # inference: fold the key projections into the query weights once per weight version
         P._folds = None
         if not self.training:
@@ -173,7 +178,7 @@ class DIGAT(GraphEncoder):
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))
-        return key
+        return key + (self.featureAffine.weight._version,)
 
     def _fold_attention(self):
         """(K x).(Q c + b) = x.(Wf c + bf) with Wf = K^T Q, bf = K^T b, computed by the library itself."""
@@ -300,6 +305,39 @@ class DIGAT(GraphEncoder):
         _lib.check(L.digat_encoder_fwd(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
                                        cm.data_ptr(), ci.data_ptr(), _lib.ptr(c0), out_n.data_ptr(), out_u.data_ptr(),
                                        B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_encoder_fwd")
+        return out_n, out_u
+
+    def inference_grouped(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                          user_category_mask, user_category_indices, row_group, news_graph_context):
+        """``inference`` for rows that share users (not in the reference: its driver expands the user tensors per
+        row, util.py:57-67).  The four user tensors are given once per GROUP ([G,...]) and ``row_group`` [B] maps
+        each row to its group; results are bit-identical to ``inference`` on the expanded tensors."""
+        Xn, ue = _lib.f32(news_graph_embeddings), _lib.f32(user_news_embedding)
+        dev = _lib.require_device(Xn, news_graph, news_graph_mask, ue, user_graph, user_category_mask,
+                                  user_category_indices, row_group)
+        B, N, d = Xn.shape
+        G = ue.shape[0]
+        H, C = self.max_history_num, self.category_num - 1
+        if 4 * G > B or self.training:                 # too few rows per group to pay off: expand and take the plain path
+            rg = row_group.long()
+            return self.inference(Xn, news_graph, news_graph_mask, ue.index_select(0, rg), user_graph.index_select(0, rg),
+                                  user_category_mask.index_select(0, rg), user_category_indices.index_select(0, rg),
+                                  news_graph_context)
+        An, Mn = _lib.as_bytes(news_graph), _lib.as_bytes(news_graph_mask)
+        Au, cm = _lib.as_bytes(user_graph), _lib.as_bytes(user_category_mask)
+        ci = user_category_indices.to(torch.int64).contiguous()
+        rg = row_group.to(torch.int32).contiguous()
+        c0 = _lib.f32(news_graph_context)
+        out_n = torch.empty((B, d), dtype=torch.float32, device=dev)
+        out_u = torch.empty((B, d), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
+        ws = _lib.workspace(nbytes, dev, "encoder")
+        P = self._params()
+        _lib.check(L.digat_encoder_fwd_grouped(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
+                                               cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(), out_n.data_ptr(),
+                                               out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                   "digat_encoder_fwd_grouped")
         return out_n, out_u
 
     def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,

@@ -81,6 +81,20 @@ class Model(nn.Module):
         return logits
 
 
+    def inference_grouped(self, user_news_embedding, user_graph, user_category_mask, user_category_indices, row_group,
+                          candidate_news_embedding, news_graph, news_graph_mask, c_n0):
+        """``inference`` with the user tensors given once per impression ([G,...]) + ``row_group`` [B]."""
+        news_rep, user_rep = self.graph_encoder.inference_grouped(candidate_news_embedding, news_graph, news_graph_mask,
+                                                                  user_news_embedding, user_graph, user_category_mask,
+                                                                  user_category_indices, row_group, c_n0)
+        B, d = news_rep.shape
+        logits = torch.empty(B, dtype=torch.float32, device=news_rep.device)
+        if B:
+            _lib.check(_lib.lib().digat_row_logits(news_rep.data_ptr(), user_rep.data_ptr(), logits.data_ptr(), B, d,
+                                                   _lib.stream_ptr()), "digat_row_logits")
+        return logits
+
+
 class PrecomputedNewsEncoder(nn.Module):
     """Stand-in producer for synthetic runs: news id -> embedding row (no title text exists).
     Takes ids shaped [B, n] or [B, n, 1] (a "title" of one token = the news id; the mask argument is ignored)

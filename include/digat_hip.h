@@ -54,6 +54,7 @@ int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b
  * (digat_split_weights_bytes(N, K) bytes) receives the split weights.  M >= 2048, N % 80 == 0, K % 8 == 0. */
 size_t digat_split_weights_bytes(int rows, int K);
 int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream);
+int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream);    /* one [N,K] matrix */
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
                        int M, int N, int K, void* wsplit, void* stream);
 
@@ -139,6 +140,7 @@ typedef struct digat_params {
     const float *cand_fold_W, *cand_fold_b;
     const float *user_news_fold_W, *user_news_fold_b;
     const float *userAtt_fold_W, *userAtt_fold_b;
+    const void  *featureAffine_wsplit;   /* optional: featureAffine.weight split by digat_split_weights (bf16x6) */
 } digat_params;
 
 /* (K x).(Q c + bQ) = x.(Wf c + bf): fold one ScaledDotProductAttention / user_news pair.
@@ -161,6 +163,22 @@ int digat_encoder_fwd(const digat_params* params,
                       float* out_news_context, float* out_user_context,
                       int B, int N, int H,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same inference for rows that SHARE users: in dev/test scoring the ~37 candidate rows of one
+ * impression carry identical user tensors (util.py:57-67 expands them per row).  Here the user side is
+ * passed once per group — user_news_embedding [G,H,d], user_graph [G,U,U], user_category_mask [G,C+1],
+ * user_category_indices [G,H] — with row_group [B] (int32, values in [0,G), 4*G <= B) naming each row's
+ * group; the news side and the context stay per row.  Layer 0's user projections then run on G*U rows
+ * instead of B*U.  Results are bit-identical to digat_encoder_fwd on the expanded tensors.  Needs the
+ * folded-query fields of digat_params. */
+size_t digat_encoder_grouped_workspace_bytes(int B, int N, int H, int C, int d, int depth);
+int digat_encoder_fwd_grouped(const digat_params* params,
+                              const float* news_graph_embeddings, const uint8_t* news_graph,
+                              const uint8_t* news_graph_mask, const float* user_news_embedding_groups,
+                              const uint8_t* user_graph_groups, const uint8_t* user_category_mask_groups,
+                              const int64_t* user_category_indices_groups, const int32_t* row_group,
+                              const float* news_graph_context, float* out_news_context, float* out_user_context,
+                              int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream);
 
 /* H1: Model.inference's last line (model.py:89): logits[b] = sum_c user_ctx[b,c] * news_ctx[b,c]. */
 int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream);

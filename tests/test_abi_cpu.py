@@ -44,11 +44,11 @@ def test_workspace_queries():
 
 
 def test_struct_layout_matches_header():
-    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 7 pointers + 6 folded-query pointers."""
+    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 7 pointers + 6 folded-query pointers + 1 split-weight pointer."""
     import ctypes
     from digat_amd import _lib
     assert ctypes.sizeof(_lib.LayerParams) == 8 * 8
-    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 8 * 8 + 6 * 8
+    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 8 * 8 + 7 * 8
 
 
 def test_module_mirrors_reference_parameter_names():

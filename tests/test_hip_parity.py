@@ -292,3 +292,25 @@ def test_devset_pipeline_scores_ranks_metrics(name):
     ranks = evaluate.impression_ranks(scores, corpus.row_impression)
     ref_ranks = evaluate.impression_ranks(fx["scores"], corpus.row_impression)
     assert (ranks == ref_ranks).mean() > 0.995                                  # only near-ties may swap
+
+
+def test_grouped_inference_is_bit_identical_to_per_row():
+    """digat_encoder_fwd_grouped (user tensors once per impression) vs digat_encoder_fwd on the expanded tensors."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=40, mean_candidates=30.0,
+                               max_candidates=80, seed=77)
+    corpus = synthetic.make_corpus(spec)
+    L = 3
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=78, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 512)
+    a = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
+    b = util.score_rows(model, dc, 0, dc.rows, 512, grouped=True)
+    assert torch.equal(a, b)
