@@ -493,6 +493,160 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
     }
 }
 
+// 1b'. The same arithmetic with the A operand kept out of LDS.  The four waves are stacked along M, so a
+// wave is the only reader of its rows of A: each lane loads the 8 consecutive k of "its" row (row l&15, k group
+// l>>4 — exactly the 16x16x32 A-fragment layout) straight from global memory as two float4, splits them in
+// registers and feeds the MFMAs.  Only the (shared) weight planes go through LDS, double-buffered, one barrier
+// per K tile.  LDS traffic per K tile drops from 123 KB to 75 KB per workgroup (MT=2), which was the co-limiter
+// of the MFMA pipe (PMC: LDS busy ~ MFMA busy in the version above).
+template <int MT, int BN>
+__global__ void __launch_bounds__(256) gemm_bf16x6d_kernel(const GemmArgs g) {
+    constexpr int BM = MT * 64;
+    constexpr int NT = BN / 16;
+    constexpr int B_PIECES = 3 * BN * 4;     // 16-byte bf16 pieces of the three B planes
+    constexpr int B_PER_T = (B_PIECES + 255) / 256;
+    __shared__ uint4 Bs[2][3][4 * BN];
+
+    const int total = g.mtiles * g.ntiles;
+    const int chunk = (total + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int kg = lane >> 4, lr = lane & 15;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int Ntot = g.nseg * g.nsegs;
+    const int seg = n0 / g.nseg;
+    const int nbase = n0 - seg * g.nseg;
+    const int ktiles = (g.K + 31) >> 5;
+    const unsigned short* const wsp = g.wsplit;
+    const long plane = (long)Ntot * g.K;
+
+    const float* arow[MT];                   // this lane's A rows (clamped: rows >= M are never stored)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int gm = m0 + wm * (MT * 16) + mt * 16 + lr;
+        gm = gm < g.M ? gm : g.M - 1;
+        arow[mt] = g.a0 + (long)gm * g.lda0 + kg * 8;
+    }
+    float4 ra[MT][2];
+    uint4 rb[B_PER_T];
+    auto load_tiles = [&](int kt) {
+        const bool kin = kt * 32 + kg * 8 < g.K;             // K % 8 == 0: an 8-group is all in or all out
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4* src = reinterpret_cast<const float4*>(arow[mt] + kt * 32);
+            ra[mt][0] = kin ? src[0] : f4_zero();
+            ra[mt][1] = kin ? src[1] : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < B_PIECES) {
+                const int p = i / (BN * 4), rem = i - p * (BN * 4);
+                const int r = rem >> 2, kq = rem & 3;
+                const int k = kt * 32 + kq * 8;
+                if (nbase + r < g.nseg && n0 + r < Ntot && k < g.K)
+                    v = *reinterpret_cast<const uint4*>(wsp + p * plane + (long)(n0 + r) * g.K + k);
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < B_PER_T; ++u) {
+            const int i = tid + u * 256;
+            if (i < B_PIECES) {
+                const int p = i / (BN * 4), rem = i - p * (BN * 4);
+                const int r = rem >> 2, kq = rem & 3;
+                Bs[buf][p][kq * BN + (r ^ kq)] = rb[u];
+            }
+        }
+    };
+    bf16x8 af[3][MT];
+    auto split_a = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const Split3f s0 = split3f(ra[mt][0].x), s1 = split3f(ra[mt][0].y), s2 = split3f(ra[mt][0].z), s3 = split3f(ra[mt][0].w);
+            const Split3f s4 = split3f(ra[mt][1].x), s5 = split3f(ra[mt][1].y), s6 = split3f(ra[mt][1].z), s7 = split3f(ra[mt][1].w);
+            af[0][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.a, s1.a), pack_hi16(s2.a, s3.a), pack_hi16(s4.a, s5.a), pack_hi16(s6.a, s7.a)));
+            af[1][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.b, s1.b), pack_hi16(s2.b, s3.b), pack_hi16(s4.b, s5.b), pack_hi16(s6.b, s7.b)));
+            af[2][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.c, s1.c), pack_hi16(s2.c, s3.c), pack_hi16(s4.c, s5.c), pack_hi16(s6.c, s7.c)));
+        }
+    };
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    load_tiles(0);
+    store_b(0);
+    split_a();
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < ktiles;
+        if (more) load_tiles(kt + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int slot = kg * BN + ((nt * 16 + lr) ^ kg);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bs[buf][0][slot]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bs[buf][1][slot]);
+            const bf16x8 b3 = __builtin_bit_cast(bf16x8, Bs[buf][2][slot]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                v4f c = acc[mt][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][mt], b1, c, 0, 0, 0);   // x3 w1
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b2, c, 0, 0, 0);   // x2 w2
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b3, c, 0, 0, 0);   // x1 w3
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b1, c, 0, 0, 0);   // x2 w1
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b2, c, 0, 0, 0);   // x1 w2
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b1, c, 0, 0, 0);   // x1 w1
+                acc[mt][nt] = c;
+            }
+        }
+        if (more) {
+            store_b(buf ^ 1);
+            split_a();
+        }
+        __syncthreads();
+    }
+
+    const float* const radd = seg == g.radd_seg ? g.radd : nullptr;
+    long rrow[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
+            rrow[mt][r] = radd ? (long)(gm / g.rows_per_b) * g.nseg : 0;
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nn = nbase + nt * 16 + (lane & 15);
+            if (nn >= g.nseg) continue;
+            const float* bp = g.bias[seg];
+            float* yp = g.y[seg];
+            const float bv = bp ? bp[nn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
+                if (gm >= g.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (radd) v = radd[rrow[mt][r] + nn] + v;
+                if (g.epi == EPI_RELU_RES) v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
+                yp[(long)gm * g.ldy + nn] = v;
+            }
+        }
+    }
+}
+
 // =================================================================================================
 // 1c. skinny linear for the [B,d] projections (M < 2048): a latency chain, not a throughput problem
 // =================================================================================================
@@ -641,10 +795,21 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
         g.k0 == g.K && !g.transW) {
-        g.mtiles = (g.M + 127) / 128;
+        static const int variant = getenv("DIGAT_GEMM_V") ? atoi(getenv("DIGAT_GEMM_V")) : 1;
         g.ntiles = (Ntot + 79) / 80;
-        hipLaunchKernelGGL((gemm_bf16x6_kernel<128, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
-                           0, st, g);
+        if (variant == 0) {
+            g.mtiles = (g.M + 127) / 128;
+            hipLaunchKernelGGL((gemm_bf16x6_kernel<128, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
+                               0, st, g);
+        } else if (variant == 1) {
+            g.mtiles = (g.M + 127) / 128;
+            hipLaunchKernelGGL((gemm_bf16x6d_kernel<2, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
+                               0, st, g);
+        } else {
+            g.mtiles = (g.M + 255) / 256;
+            hipLaunchKernelGGL((gemm_bf16x6d_kernel<4, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
+                               0, st, g);
+        }
         DIGAT_CHECK_LAUNCH();
         return DIGAT_OK;
     }
@@ -979,6 +1144,74 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     }
 }
 
+// Score kernel for SMALL graphs (n <= 16: the news graph, N = 10 by default).  The tile kernel above would
+// keep 72 of 256 threads busy there and pay a barrier + DMA round trip per 20-channel chunk; with so little
+// arithmetic the job is a latency problem.  Here one WAVE owns one (row, centre i): the lanes span the channels
+// (float4 each, coalesced), Q_i and a stay in registers, every neighbour's P'_j streams through once, the
+// per-pair channel sum is a wave reduction, lane j keeps score j, and the masked softmax is the same
+// shuffle code as above.  No LDS, no barrier; B*n waves (10 240 for the default batch).
+template <int U>   // float4 pieces per lane: d <= 256 * U
+__global__ void __launch_bounds__(256) xattn_score_small_kernel(const ScoreArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rho = (long)blockIdx.x * 4 + wave;
+    const int n = g.n, d4 = g.d4;
+    if (rho >= (long)g.B * n) return;
+    const long b = rho / n;
+    const float4* a4 = reinterpret_cast<const float4*>(g.a);
+    const float4* Qi = reinterpret_cast<const float4*>(g.Q) + rho * d4;
+    const float4* Pb = reinterpret_cast<const float4*>(g.P) + b * n * d4;
+    float4 q[U], av[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c4 = lane + 64 * u;
+        q[u] = c4 < d4 ? Qi[c4] : f4_zero();
+        av[u] = c4 < d4 ? a4[c4] : f4_zero();          // a = 0 on the padding channels: they add nothing
+    }
+    const bool edge = lane < n && g.A[rho * n + lane] != 0;
+    float mine = 0.f;
+    auto pair_sum = [&](const float4 (&p)[U]) -> float {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            part = fmaf(av[u].x, fmaxf(p[u].x + q[u].x, 0.f), part);
+            part = fmaf(av[u].y, fmaxf(p[u].y + q[u].y, 0.f), part);
+            part = fmaf(av[u].z, fmaxf(p[u].z + q[u].z, 0.f), part);
+            part = fmaf(av[u].w, fmaxf(p[u].w + q[u].w, 0.f), part);
+        }
+        return wave_sum(part);
+    };
+    int j = 0;
+    for (; j + 2 <= n; j += 2) {                        // two neighbours' rows in flight
+        float4 p0[U], p1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c4 = lane + 64 * u;
+            p0[u] = c4 < d4 ? Pb[(long)j * d4 + c4] : f4_zero();
+            p1[u] = c4 < d4 ? Pb[(long)(j + 1) * d4 + c4] : f4_zero();
+        }
+        const float s0 = pair_sum(p0), s1 = pair_sum(p1);
+        if (lane == j) mine = s0;
+        if (lane == j + 1) mine = s1;
+    }
+    if (j < n) {
+        float4 p0[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c4 = lane + 64 * u;
+            p0[u] = c4 < d4 ? Pb[(long)j * d4 + c4] : f4_zero();
+        }
+        const float s0 = pair_sum(p0);
+        if (lane == j) mine = s0;
+    }
+    if (edge && g.s_out) g.s_out[rho * n + lane] = mine;
+    const float lk = mine > 0.f ? mine : 0.2f * mine;
+    const float v0 = lane < n ? (edge ? lk : -1e9f) : -INFINITY;     // masked: -1e9, not -inf (a row without edges -> uniform)
+    const float m = wave_max(v0);
+    const float e0 = lane < n ? expf(v0 - m) : 0.f;
+    const float inv = wave_sum(e0);
+    if (lane < n) g.alpha[rho * n + lane] = e0 / inv;
+}
+
 // Aggregation kernel: out[b] = relu(alpha[b] @ h[b]) + X[b] on the fp32 matrix cores
 // (v_mfma_f32_16x16x4_f32 is an exact k-ordered fma chain, so this equals a sequential sum over the
 // neighbours j).  One workgroup owns one row b: alpha[b] (n*n floats) is staged in LDS once, each wave
@@ -1134,6 +1367,30 @@ static int plan_xattn(int B, int n, int d, XattnPlan* pl) {
     return DIGAT_OK;
 }
 
+// the score launch of a filled-in plan: the wave-per-centre kernel for small graphs, the tile kernel otherwise
+static int launch_score(const XattnPlan& pl, hipStream_t st) {
+    const ScoreArgs& g = pl.g;
+    if (g.n <= 16 && g.d4 <= 256 && !g.skip) {
+        const unsigned blocks = (unsigned)(((long)g.B * g.n + 3) / 4);
+        if (g.d4 <= 64) hipLaunchKernelGGL(xattn_score_small_kernel<1>, dim3(blocks), dim3(256), 0, st, g);
+        else if (g.d4 <= 128) hipLaunchKernelGGL(xattn_score_small_kernel<2>, dim3(blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(xattn_score_small_kernel<4>, dim3(blocks), dim3(256), 0, st, g);
+        DIGAT_CHECK_LAUNCH();
+        return DIGAT_OK;
+    }
+    if (pl.lds > 64 * 1024) {
+        static int raised = 0;     // benign race: the attribute is idempotent
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)xattn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
+            raised = 1;
+        }
+    }
+    hipLaunchKernelGGL(xattn_score_kernel, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, pl.g);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
 // Pr = K3 + K1 (r already added to the neighbour-side projection), see xattn_core
 static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h, const float* X,
                                  const float* a, const uint8_t* A, float* out, float* alpha,
@@ -1151,16 +1408,8 @@ static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h
     if (!(pl.g.skip & 32)) {
         // algorithmic bytes of the score launch: P', Q in (2 n d floats), adjacency, alpha out, a
         ProfScope prof(DIGAT_KERNEL_XATTN, (double)B * (2.0 * n * d * 4 + (double)n * n * 5.0) + 4.0 * d, st);
-        if (pl.lds > 64 * 1024) {
-            static int raised = 0;     // benign race: the attribute is idempotent
-            if (!raised) {
-                if (hipFuncSetAttribute((const void*)xattn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
-                raised = 1;
-            }
-        }
-        hipLaunchKernelGGL(xattn_score_kernel, dim3(pl.blocks), dim3(pl.threads), pl.lds, st, pl.g);
-        DIGAT_CHECK_LAUNCH();
+        const int rc2 = launch_score(pl, st);
+        if (rc2) return rc2;
     }
     if (!(pl.g.skip & 2)) {
         AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1};
