@@ -1495,67 +1495,152 @@ struct TopicArgs {
     const float* Xu; long ld_b; const float* kq; const int64_t* idx; float* out;
     int B, H, C1, d; float sqrt_d;
     float* alpha_out;                    // optional [B,H]: the segment-softmax weights (training)
+    int skip;                            // ablation only (env DIGAT_TOPIC_SKIP, 0 in production)
 };
 constexpr int TOPIC_MAX_H = 256;
+constexpr int TOPIC_MAX_CT = 4;          // 16-row category tiles: category_num + 1 <= 64
 
-__global__ void __launch_bounds__(256) topic_pool_kernel(const TopicArgs g) {
-    __shared__ float sa[TOPIC_MAX_H];
-    __shared__ float sal[TOPIC_MAX_H];
-    __shared__ int sidx[TOPIC_MAX_H];
+// One workgroup per row, one wave per 64 channels (7 waves at d = 400).
+//  1. scores a_t = x_t . kq / sqrt(d): a wave takes four history rows at a time (all their loads in flight),
+//     lanes span the channels, one wave reduction per row;
+//  2. segment softmax over the rows of equal category (H threads, O(H^2) LDS reads) -> the [C1, H] matrix
+//     M[c][t] = alpha_t if idx_t == c else 0 in LDS;
+//  3. out = M @ X on the fp32 matrix cores: v_mfma_f32_16x16x4_f32 is an exact k-ordered fma chain and
+//     fma(0, x, acc) = acc, so out[c] is the sum over the rows of category c in ascending t — the CPU
+//     scatter_add order — while X streams through once, coalesced, prefetched (the scalar version of this
+//     phase walked H dependent, branchy loads per output).  Lane layout as in xattn_agg_kernel: MFMA column
+//     l&15 of channel tile s is channel c0 + 4*(l&15) + s, so X loads and output stores are float4.
+__global__ void __launch_bounds__(1024) topic_pool_kernel(const TopicArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = g.H, hs = H | 1;
+    const int ct = (g.C1 + 15) >> 4;
+    float* M = reinterpret_cast<float*>(smem);               // [ct*16][hs]
+    float* sa = M + ct * 16 * hs;                            // [H]
+    int* sidx = reinterpret_cast<int*>(sa + H);              // [H]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int d4 = g.d >> 2, H = g.H;
-    const float4* F4 = reinterpret_cast<const float4*>(g.Xu + (long)b * g.ld_b);
+    const int nthreads = blockDim.x, nw = nthreads >> 6;
+    const int d4 = g.d >> 2;
+    const float* Xb = g.Xu + (long)b * g.ld_b;
+    const float4* F4 = reinterpret_cast<const float4*>(Xb);
     const float4* K4 = reinterpret_cast<const float4*>(g.kq + (long)b * g.d);
-    for (int t = tid; t < H; t += 256) {
+    for (int t = tid; t < H; t += nthreads) {
         const long v = g.idx[(long)b * H + t];
         sidx[t] = (v >= 0 && v < g.C1) ? (int)v : -1;
     }
-    for (int t = wave; t < H; t += 4) {
-        float part = 0.f;
+    for (int i = tid; i < ct * 16 * hs; i += nthreads) M[i] = 0.f;
+    for (int t0 = wave; t0 < ((g.skip & 1) ? 0 : H); t0 += 4 * nw) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c4 = lane; c4 < d4; c4 += 64) {
-            const float4 x = F4[(long)t * d4 + c4], k = K4[c4];
-            part = fmaf(x.w, k.w, fmaf(x.z, k.z, fmaf(x.y, k.y, fmaf(x.x, k.x, part))));
+            const float4 k = K4[c4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + r * nw;
+                if (t < H) {
+                    const float4 x = F4[(long)t * d4 + c4];
+                    part[r] = fmaf(x.w, k.w, fmaf(x.z, k.z, fmaf(x.y, k.y, fmaf(x.x, k.x, part[r]))));
+                }
+            }
         }
-        part = wave_sum(part);
-        if (lane == 0) sa[t] = part / g.sqrt_d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + r * nw;
+            const float s = wave_sum(part[r]);
+            if (lane == 0 && t < H) sa[t] = s / g.sqrt_d;
+        }
     }
     __syncthreads();
-    for (int t = tid; t < H; t += 256) {
+    for (int t = tid; t < ((g.skip & 2) ? 0 : H); t += nthreads) {
         const int s = sidx[t];
         float m = -INFINITY;
         for (int u = 0; u < H; ++u) if (sidx[u] == s) m = fmaxf(m, sa[u]);
         float den = 0.f;
         for (int u = 0; u < H; ++u) if (sidx[u] == s) den += expf(sa[u] - m);
-        sal[t] = s >= 0 ? expf(sa[t] - m) / den : 0.f;
-        if (g.alpha_out) g.alpha_out[(long)b * H + t] = sal[t];
+        const float al = s >= 0 ? expf(sa[t] - m) / den : 0.f;
+        if (s >= 0) M[s * hs + t] = al;
+        if (g.alpha_out) g.alpha_out[(long)b * H + t] = al;
     }
     __syncthreads();
-    // out[c][:] = sum over t with idx_t == c, in ascending t (the CPU scatter_add order)
-    const int total = g.C1 * d4;
-    for (int o = tid; o < total; o += 256) {
-        const int c = o / d4, c4 = o - c * d4;
-        float4 acc = f4_zero();
-        for (int t = 0; t < H; ++t) {
-            if (sidx[t] == c) {
-                const float al = sal[t];
-                const float4 x = F4[(long)t * d4 + c4];
-                acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
-                acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ch = wave * 64 + 4 * lr;
+    const bool ch_ok = ch < g.d;             // no early exit: the MFMAs need every lane's operand rows
+    const int nsteps = (g.skip & 4) ? 0 : (H + 3) >> 2;
+    auto load_x = [&](int step) -> float4 {
+        const int j = step * 4 + lq;
+        return (j < H && ch_ok) ? *reinterpret_cast<const float4*>(Xb + (long)j * g.d + ch) : f4_zero();
+    };
+    constexpr int PF = 4;
+    v4f acc[TOPIC_MAX_CT][4];
+#pragma unroll
+    for (int it = 0; it < TOPIC_MAX_CT; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[it][s] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float4 xq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) xq[u] = load_x(u);
+    for (int step = 0; step < nsteps; step += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int st = step + u;
+            if (st < nsteps) {
+                const float4 xc = xq[u];
+                xq[u] = load_x(st + PF);
+                const int j = st * 4 + lq;
+#pragma unroll
+                for (int it = 0; it < TOPIC_MAX_CT; ++it) {
+                    if (it < ct) {
+                        const float av = j < H ? M[(it * 16 + lr) * hs + j] : 0.f;
+                        acc[it][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.x, acc[it][0], 0, 0, 0);
+                        acc[it][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.y, acc[it][1], 0, 0, 0);
+                        acc[it][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.z, acc[it][2], 0, 0, 0);
+                        acc[it][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.w, acc[it][3], 0, 0, 0);
+                    }
+                }
             }
         }
-        reinterpret_cast<float4*>(g.out + ((long)b * g.C1 + c) * g.d)[c4] = acc;
     }
+    float* Ob = g.out + (long)b * g.C1 * g.d;
+#pragma unroll
+    for (int it = 0; it < TOPIC_MAX_CT; ++it) {
+        if (it < ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = it * 16 + 4 * lq + r;
+                if (c < g.C1 && ch_ok)
+                    *reinterpret_cast<float4*>(Ob + (long)c * g.d + ch) =
+                        make_float4(acc[it][0][r], acc[it][1][r], acc[it][2][r], acc[it][3][r]);
+            }
+        }
+    }
+}
+
+static int launch_topic_args(TopicArgs g, hipStream_t st) {
+    static int skip = -1;
+    if (skip < 0) { const char* e = getenv("DIGAT_TOPIC_SKIP"); skip = e ? atoi(e) : 0; }
+    g.skip = skip;
+    const int groups = (g.d + 63) / 64;
+    const int ct = (g.C1 + 15) / 16;
+    if (g.H > TOPIC_MAX_H || g.d % 4 || groups > 16 || ct > TOPIC_MAX_CT) return DIGAT_ERR_SHAPE;
+    const size_t lds = ((size_t)ct * 16 * (g.H | 1) + 2 * (size_t)g.H) * 4;
+    if (lds > 64 * 1024) {
+        static int raised = 0;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)topic_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return DIGAT_ERR_LAUNCH;
+            raised = 1;
+        }
+    }
+    hipLaunchKernelGGL(topic_pool_kernel, dim3(g.B), dim3(64 * groups), lds, st, g);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
 }
 
 static int launch_topic(const float* Xu, long ld_b, const float* kq, const int64_t* idx, float* out,
                         int B, int H, int C1, int d, hipStream_t st) {
-    if (H > TOPIC_MAX_H || d % 4) return DIGAT_ERR_SHAPE;
     if (B == 0) return DIGAT_OK;
-    TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d), nullptr};
+    TopicArgs g{Xu, ld_b, kq, idx, out, B, H, C1, d, sqrtf((float)d), nullptr, 0};
     ProfScope prof(DIGAT_KERNEL_TOPIC, (double)B * ((double)H * d * 4 + d * 4.0 + H * 8.0 + (double)C1 * d * 4), st);
-    hipLaunchKernelGGL(topic_pool_kernel, dim3(B), dim3(256), 0, st, g);
-    DIGAT_CHECK_LAUNCH();
-    return DIGAT_OK;
+    return launch_topic_args(g, st);
 }
 
 // =================================================================================================

@@ -90,6 +90,24 @@ def bench_linear(M=68608, N=400, K=400):
     print(f"   (rocBLAS addmm for scale: {t_ref*1e3:.1f} us, max|diff| {float((ref - y).abs().max()):.2e})")
 
 
+def bench_topic(B=1024, H=50, C=17, d=400):
+    dev = torch.device("cuda:0")
+    U = H + C
+    Xu = torch.randn(B, U, d, device=dev)
+    kq = torch.randn(B, d, device=dev)
+    idx = torch.randint(0, C + 1, (B, H), device=dev, dtype=torch.int64)
+    out = torch.empty(B, C + 1, d, device=dev)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.digat_topic_pool_fwd(Xu.data_ptr(), kq.data_ptr(), idx.data_ptr(), out.data_ptr(), B, U, H, C + 1, d,
+                                          _lib.stream_ptr()), "topic")
+    med, best = timeit(run)
+    by = B * (H * d * 4 + d * 4 + H * 8 + (C + 1) * d * 4)
+    print(f"topic B={B} H={H} C1={C+1} d={d} skip={os.environ.get('DIGAT_TOPIC_SKIP', '0')}: median {med*1e3:.1f} us best {best*1e3:.1f} us "
+          f"{by/med/1e6:.0f} GB/s algorithmic ({by/1e6:.0f} MB)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "xattn"
     nums = [int(v) for v in sys.argv[2:]]
@@ -97,5 +115,7 @@ if __name__ == "__main__":
         bench_xattn(*nums)
     elif what == "xattn-mind":
         bench_xattn(*nums, density="mind")
+    elif what == "topic":
+        bench_topic(*nums)
     elif what == "linear":
         bench_linear(*nums)
