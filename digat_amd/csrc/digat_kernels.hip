@@ -68,6 +68,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// one 16-byte-per-lane global -> LDS copy; LDS address = lds_byte_addr (wave-uniform) + 16*lane.
+// Invisible to hipcc's waitcnt bookkeeping: completion is counted by hand (wait_vmcnt below).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
 // =================================================================================================
 // 1. fp32 MFMA GEMM:  y_s[M, nseg] = A[M,K] @ w_s[nseg,K]^T (+ bias_s), s < nsegs, fused epilogue
 // =================================================================================================
@@ -83,6 +100,7 @@ struct GemmArgs {
     int mtiles, ntiles;
     const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
     const float* radd; int radd_seg, rows_per_b;   // segment radd_seg: y += radd[row / rows_per_b][col]  (K3 + K1 of Eq. 8)
+    int dbg;                                       // ablation only (env DIGAT_GEMM_DBG): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int m_dispatch;                                // != 0: choose the kernel as if M were this (bit-identical results across batchings)
 };
 
@@ -647,7 +665,238 @@ __global__ void __launch_bounds__(256) gemm_bf16x6d_kernel(const GemmArgs g) {
     }
 }
 
-// =================================================================================================
+// 1b''. Strip-mined version.  PMC on the kernel above: 3.8 non-MFMA vector instructions per MFMA (the
+// operand split is 88 per K tile and wave, address arithmetic and bounds checks as much again), while a
+// 16-cycle MFMA leaves room for two — the vector pipe, not the matrix pipe, set the pace.  So:
+//  * one wave keeps its 32 rows of A for THREE 80-column strips of the weights (wave tile 32 x 240, 120
+//    accumulator registers): the split is paid once per 180 MFMAs instead of once per 60;
+//  * the weights are pre-arranged (split_weights_tiled_kernel) as ready-made LDS images, one per (80-column
+//    strip, K tile): [plane][k group][row] 16-byte slots, K zero-padded to 32.  A strip image is 15 KB and
+//    goes global -> LDS by LDS-DMA (no registers, no address arithmetic, no bounds checks), double-buffered:
+//    the image of step j+1 is in flight while step j's 60 MFMAs run; one s_waitcnt + one s_barrier per step;
+//  * the A rows of the next K tile are loaded at strip 0 and split in the shadow of strips 1 and 2.
+// Tiles may span weight segments (the epilogue picks bias/output per strip; segments are multiples of 80).
+constexpr int WS_SLOTS = 960;            // 16-byte slots of one strip image: 3 planes x 4 k groups x 80 rows
+
+__global__ void __launch_bounds__(256) split_weights_tiled_kernel(const float* w0, const float* w1, const float* w2,
+                                                                  int nseg, int nsegs, int K, unsigned short* out) {
+    const int KT = (K + 31) >> 5, Kp = KT * 32;
+    const int Ntot = nseg * nsegs;
+    const int strips = (Ntot + 79) / 80;
+    const long total = (long)strips * 80 * Kp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+        float v = 0.f;
+        if (n < Ntot && k < K) {
+            const int seg = n / nseg;
+            const float* w = seg == 0 ? w0 : (seg == 1 ? w1 : w2);
+            v = w[(long)(n - seg * nseg) * K + k];
+        }
+        const Split3 sp = split3(v);
+        const int strip = n / 80, r = n - strip * 80, kt = k >> 5, kq = (k >> 3) & 3, e = k & 7;
+        const long base = ((long)strip * KT + kt) * WS_SLOTS * 8;
+        out[base + ((0 * 4 + kq) * 80 + r) * 8 + e] = sp.a;
+        out[base + ((1 * 4 + kq) * 80 + r) * 8 + e] = sp.b;
+        out[base + ((2 * 4 + kq) * 80 + r) * 8 + e] = sp.c;
+    }
+}
+
+template <int NSUB>
+__global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) {
+    constexpr int MT = 2, NT = 5;
+    constexpr int RING = 3;                  // strip images in LDS: two in flight behind the one being read
+    constexpr int ABUF = NSUB == 1 ? 2 : 1;  // fp32 A tiles (128 rows x 32 k) in LDS
+    __shared__ uint4 Bs[RING][WS_SLOTS];
+    __shared__ uint4 As[ABUF][1024];         // slot r*8 + (c4 ^ ((r>>1)&7)): conflict-free 32-byte row pieces
+
+    const int total = g.mtiles * g.ntiles;
+    const int chunk = (total + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int kg = lane >> 4, lr = lane & 15;
+    const int m0 = mtile * 128;
+    const int strip0 = ntile * NSUB;
+    const int KT = (g.K + 31) >> 5;
+    const int nsteps = KT * NSUB;
+    const unsigned ldsB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Bs[0][0];
+    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&As[0][0];
+    const char* const wimg = reinterpret_cast<const char*>(g.wsplit) + (long)lane * 16;
+    const int wu = __builtin_amdgcn_readfirstlane(wm);          // the DMA's LDS address goes through M0: provably uniform
+
+    // Every global read of the loop is an LDS-DMA, four wave-instructions per wave and image, so the vector-memory
+    // queue holds whole images in issue order and "s_waitcnt vmcnt(4)" means "all but the youngest image".
+    auto issue_b = [&](int step) {           // strip image of step (kt, s) -> Bs[step % RING]; 15 instructions + 1 repeat
+        const int kt = step / NSUB, s = step - kt * NSUB;
+        const int buf = step % RING;
+        const char* src = wimg + ((long)(strip0 + s) * KT + kt) * (WS_SLOTS * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int q = wu + 4 * k;
+            q = q < 15 ? q : 14;                                 // wave 3 copies piece 14 twice: four per wave, always
+            lds_dma16(reinterpret_cast<const float*>(src + q * 1024), ldsB + (unsigned)((buf * WS_SLOTS + q * 64) * 16));
+        }
+    };
+    const float* asrc[4];                    // this lane's source of A-tile piece q = wu + 4k at K tile 0
+    int ac4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sl = (wm + 4 * k) * 64 + lane;
+        const int r = sl >> 3, c4 = (sl & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r;
+        gm = gm < g.M ? gm : g.M - 1;                            // rows >= M are never stored
+        asrc[k] = g.a0 + (long)gm * g.lda0 + c4 * 4;
+        ac4[k] = c4 * 4;
+    }
+    auto issue_a = [&](int kt, int abuf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // K % 8 == 0, K >= 32; a float4 past K reads the row start instead (finite) and meets zero weights
+            const int ko = kt * 32 + ac4[k] < g.K ? kt * 32 : 0;
+            lds_dma16(asrc[k] + ko, ldsA + (unsigned)((abuf * 1024 + (wu + 4 * k) * 64) * 16));
+        }
+    };
+    auto split_half = [&](const float4& v, unsigned (&o)[3][2]) {
+        const Split3f s0 = split3f(v.x), s1 = split3f(v.y), s2 = split3f(v.z), s3 = split3f(v.w);
+        o[0][0] = pack_hi16(s0.a, s1.a); o[0][1] = pack_hi16(s2.a, s3.a);
+        o[1][0] = pack_hi16(s0.b, s1.b); o[1][1] = pack_hi16(s2.b, s3.b);
+        o[2][0] = pack_hi16(s0.c, s1.c); o[2][1] = pack_hi16(s2.c, s3.c);
+    };
+    auto split_mt = [&](int mt, int abuf, bf16x8 (&dst)[3][MT]) {     // this lane's 8 k of row (mt, lr): LDS -> 3 bf16 fragments
+        const int r = wm * 32 + mt * 16 + lr;
+        const int sw = (r >> 1) & 7;
+        const float4 v0 = __builtin_bit_cast(float4, As[abuf][r * 8 + ((kg * 2) ^ sw)]);
+        const float4 v1 = __builtin_bit_cast(float4, As[abuf][r * 8 + ((kg * 2 + 1) ^ sw)]);
+        unsigned lo[3][2], hi[3][2];
+        split_half(v0, lo);
+        split_half(v1, hi);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p][mt] = __builtin_bit_cast(bf16x8, make_uint4(lo[p][0], lo[p][1], hi[p][0], hi[p][1]));
+    };
+
+    v4f acc[NSUB][MT][NT];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[s][mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[3][MT], afn[3][MT];
+    issue_a(0, 0);
+    issue_b(0);
+    if (nsteps > 1) issue_b(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    split_mt(0, 0, af);
+    split_mt(1, 0, af);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int step = kt * NSUB + s;
+            const int buf = step % RING;
+            // queue, oldest first: image(step) | A tile requested a step ago | image(step+1): only the last may stay in flight
+            if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();        // landed for every wave; image(step-1) and the old A tile are free
+            if (NSUB == 1) {
+                if (kt > 0) { split_mt(0, kt & 1, af); split_mt(1, kt & 1, af); }    // requested a step ago, into the other buffer
+                if (more && !(g.dbg & 1)) issue_a(kt + 1, (kt + 1) & 1);
+            } else if (s == 0 && more && !(g.dbg & 1)) {
+                issue_a(kt + 1, 0);                                // read at strip 1, after the next barrier
+            }
+            if (step + 2 < nsteps && !(g.dbg & 1)) issue_b(step + 2);
+            const uint4* Bi = Bs[buf];
+            const int lslot = kg * 80 + lr;
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[0][p] = __builtin_bit_cast(bf16x8, Bi[p * 320 + ((g.dbg & 16) ? 0 : lslot)]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + 1 < NT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bq[(nt + 1) & 1][p] = __builtin_bit_cast(bf16x8, Bi[p * 320 + lslot + (nt + 1) * 16]);
+                }
+                const bf16x8 b1 = bq[nt & 1][0], b2 = bq[nt & 1][1], b3 = bq[nt & 1][2];
+                v4f c0 = acc[s][0][nt], c1 = acc[s][1][nt];
+                if (!(g.dbg & 4)) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[2][0], c0, 0, 0, 0);   // x3 w1
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[2][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[1][0], c0, 0, 0, 0);   // x2 w2
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[1][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b3, af[0][0], c0, 0, 0, 0);   // x1 w3
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b3, af[0][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[1][0], c0, 0, 0, 0);   // x2 w1
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[1][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[0][0], c0, 0, 0, 0);   // x1 w2
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[0][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[0][0], c0, 0, 0, 0);   // x1 w1
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[0][1], c1, 0, 0, 0);
+                } else { c0[0] += (float)b1[0] + (float)b2[1] + (float)b3[2] + (float)af[0][0][0]; c1[1] += (float)af[1][1][1] + (float)af[2][0][1]; }
+                acc[s][0][nt] = c0; acc[s][1][nt] = c1;
+                if (NSUB > 1 && more) {      // the next K tile's rows landed at this step's wait (requested at strip 0)
+                    if (s == 1 && nt == 1) split_mt(0, 0, afn);
+                    if (s == 1 && nt == 3) split_mt(1, 0, afn);
+                }
+            }
+        }
+        if (NSUB > 1 && more) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[p][mt] = afn[p][mt];
+        }
+    }
+
+    if (g.dbg & 32) {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) sum += acc[s][mt][nt][0] + acc[s][mt][nt][1] + acc[s][mt][nt][2] + acc[s][mt][nt][3];
+        g.y[0][(long)(m0 + wm * 32 + lr) * g.ldy + kg] = sum;
+        return;
+    }
+    // The weights are the MFMA's row operand, the activations its column operand, so a lane ends up with four
+    // CONSECUTIVE output columns (4*kg .. 4*kg+3 of each 16-column block) of one row (lr): float4 bias / residual
+    // loads and float4 stores, a quarter of the instructions of the row-major accumulator layout.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int gm = m0 + wm * 32 + mt * 16 + lr;
+        if (gm >= g.M) continue;
+        const long rb = g.radd ? (long)(gm / g.rows_per_b) * g.nseg : 0;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int ncol0 = (strip0 + s) * 80;         // first column of this strip in the stacked output
+            const int seg = ncol0 / g.nseg;
+            const int nbase = ncol0 - seg * g.nseg + kg * 4;
+            const float* bp = g.bias[seg];
+            const float* rrow = (g.radd && seg == g.radd_seg) ? g.radd + rb : nullptr;
+            const float* erow = g.epi == EPI_RELU_RES ? g.e0 + (long)gm * g.lde0 : nullptr;
+            float* yrow = g.y[seg] + (long)gm * g.ldy;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nn = nbase + nt * 16;
+                const v4f a = acc[s][mt][nt];
+                float4 v = make_float4(a[0], a[1], a[2], a[3]);
+                if (bp) v = f4_add(v, *reinterpret_cast<const float4*>(bp + nn));
+                if (rrow) v = f4_add(*reinterpret_cast<const float4*>(rrow + nn), v);
+                if (erow) {
+                    const float4 x = *reinterpret_cast<const float4*>(erow + nn);
+                    v = make_float4(fmaxf(v.x, 0.f) + x.x, fmaxf(v.y, 0.f) + x.y, fmaxf(v.z, 0.f) + x.z, fmaxf(v.w, 0.f) + x.w);
+                }
+                if (!(g.dbg & 8) || v.x == 12345.678f) *reinterpret_cast<float4*>(yrow + nn) = v;
+            }
+        }
+    }
+}
+
 // 1c. skinny linear for the [B,d] projections (M < 2048): a latency chain, not a throughput problem
 // =================================================================================================
 // 32x80 output tile per workgroup; the four waves split K (16-wide k blocks, wave w takes blocks
@@ -763,6 +1012,11 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
     }
 }
 
+static int gemm_variant() {      // development switch; 3 = strip-mined kernel (wide tiles always), 4 = wide only when the grid is large
+    static const int v = getenv("DIGAT_GEMM_V") ? atoi(getenv("DIGAT_GEMM_V")) : 3;
+    return v;
+}
+
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
@@ -793,9 +1047,24 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         return DIGAT_OK;
     }
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
-    if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
+    if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.K >= 32 && g.ldy % 4 == 0 && g.lde0 % 4 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
         g.k0 == g.K && !g.transW) {
-        static const int variant = getenv("DIGAT_GEMM_V") ? atoi(getenv("DIGAT_GEMM_V")) : 1;
+        const int variant = gemm_variant();
+        { static const int dbg = getenv("DIGAT_GEMM_DBG") ? atoi(getenv("DIGAT_GEMM_DBG")) : 0; g.dbg = dbg; }
+        if (variant >= 3) {
+            const int strips = Ntot / 80;
+            g.mtiles = (g.M + 127) / 128;
+            const bool wide = strips % 3 == 0 && (variant == 3 || (long)g.mtiles * (strips / 3) >= 512);
+            if (wide) {
+                g.ntiles = strips / 3;
+                hipLaunchKernelGGL((gemm_bf16x6s_kernel<3>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
+            } else {
+                g.ntiles = strips;
+                hipLaunchKernelGGL((gemm_bf16x6s_kernel<1>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
+            }
+            DIGAT_CHECK_LAUNCH();
+            return DIGAT_OK;
+        }
         g.ntiles = (Ntot + 79) / 80;
         if (variant == 0) {
             g.mtiles = (g.M + 127) / 128;
@@ -881,22 +1150,6 @@ struct ScoreArgs {
 constexpr int XA_RING = 3;   // chunk images in the LDS ring
 constexpr int XA_KMAX = 4;   // DMA wave-instructions one wave issues per chunk (upper bound)
 
-// one 16-byte-per-lane global -> LDS copy; LDS address = lds_byte_addr (wave-uniform) + 16*lane.
-// Invisible to hipcc's waitcnt bookkeeping: completion is counted by hand (wait_vmcnt below).
-__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    }
-}
 
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) xattn_score_kernel(const ScoreArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1777,40 +2030,38 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
 }
 
 // ---- bf16x6 weight preparation + a directly callable linear (tests, micro-benchmarks) --------------
-size_t digat_split_weights_bytes(int rows, int K) { return (size_t)3 * rows * K * 2; }
+size_t digat_split_weights_bytes(int rows, int K) {
+    const size_t tiled = (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;
+    const size_t planes = (size_t)3 * rows * K * 2;
+    return tiled > planes ? tiled : planes;
+}
 
-int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream) {
-    if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;
-    const long total = (long)3 * d * d;
+static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st) {
+    const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, F1, F2, d, 3, d,
-                       (unsigned short*)wsplit);
+    if (gemm_variant() >= 3) hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
+    else hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
 
+int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream) {
+    if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;
+    return launch_split(W, F1, F2, d, 3, d, wsplit, (hipStream_t)stream);
+}
+
 int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream) {
     if (!W || !wsplit || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
-    const long total = (long)N * K;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, W, W, N, 1, K,
-                       (unsigned short*)wsplit);
-    DIGAT_CHECK_LAUNCH();
-    return DIGAT_OK;
+    return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream);
 }
 
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
                        int M, int N, int K, void* wsplit, void* stream) {
     if (!x || !w || !y || !wsplit || M < 0 || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
     if (K % 8 || ldx % 4 || N % 80) return DIGAT_ERR_SHAPE;
-    const long total = (long)N * K;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, w, w, N, 1, K,
-                       (unsigned short*)wsplit);
-    DIGAT_CHECK_LAUNCH();
+    const int rcs = launch_split(w, w, w, N, 1, K, wsplit, (hipStream_t)stream);
+    if (rcs) return rcs;
     GemmArgs g = gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0);
     g.wsplit = (const unsigned short*)wsplit;
     if (M < 2048) return DIGAT_ERR_SHAPE;      // the bf16x6 kernel serves the big projections only
