@@ -100,7 +100,6 @@ struct GemmArgs {
     int mtiles, ntiles;
     const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
     const float* radd; int radd_seg, rows_per_b;   // segment radd_seg: y += radd[row / rows_per_b][col]  (K3 + K1 of Eq. 8)
-    int dbg;                                       // ablation only (env DIGAT_GEMM_DBG): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int m_dispatch;                                // != 0: choose the kernel as if M were this (bit-identical results across batchings)
 };
 
@@ -316,10 +315,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 // the six partial products whose weight is >= 2^-16 (x1w1, x1w2, x2w1, x1w3, x2w2, x3w1) are summed in
 // the fp32 MFMA accumulator (v_mfma_f32_16x16x32_bf16).  Dropped terms are <= 3 * 2^-24 relative, i.e.
 // the result is as accurate as an fp32 fma chain (measured: mean error 0.6x that of an fp32 GEMM) at
-// 6/16 of the fp32-MFMA cost.  Weights arrive pre-split (split_weights_kernel, once per weight version),
-// activations are split while they are staged into LDS.  Tiling, XCD-aware tile order and epilogue are
-// those of gemm_f32_kernel; LDS image per plane: 16-byte slots [kg][row ^ kg] (kg = 8-wide k group of the
-// 32-deep K tile), which keeps the ds_read_b128 of a lane (row l&15, kg l>>4) conflict-free.
+// 6/16 of the fp32-MFMA cost.  Weights are split once per weight version (split_weights_tiled_kernel),
+// activations while they pass through the kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Exact 3-way split by TRUNCATION: x1 = top 16 bits of v, r1 = v - x1 (exact, <= 16 significant bits),
@@ -348,334 +345,23 @@ __device__ __forceinline__ Split3 split3(float v) {
     return o;
 }
 
-// out[p][n][k] for the rows of up to three [nseg,K] weight matrices stacked along n
-__global__ void __launch_bounds__(256) split_weights_kernel(const float* w0, const float* w1, const float* w2,
-                                                            int nseg, int nsegs, int K, unsigned short* out) {
-    const long total = (long)nseg * nsegs * K;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / K;
-        const int k = (int)(i - n * K);
-        const int seg = (int)(n / nseg);
-        const float* w = seg == 0 ? w0 : (seg == 1 ? w1 : w2);
-        const Split3 sp = split3(w[(n - (long)seg * nseg) * K + k]);
-        out[i] = sp.a; out[total + i] = sp.b; out[2 * total + i] = sp.c;
-    }
-}
-
-template <int BM, int BN>
-__global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const GemmArgs g) {
-    constexpr int MT = BM / 4 / 16;          // 4 waves stacked along M
-    constexpr int NT = BN / 16;
-    constexpr int A_PER_T = BM * 8 / 256;    // float4 pieces of the fp32 A tile per thread
-    constexpr int B_PIECES = 3 * BN * 4;     // 16-byte bf16 pieces of the three B planes
-    constexpr int B_PER_T = (B_PIECES + 255) / 256;
-    __shared__ uint4 As[3][4 * BM];
-    __shared__ uint4 Bs[3][4 * BN];
-
-    const int total = g.mtiles * g.ntiles;
-    const int chunk = (total + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (tile >= total) return;
-    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
-
-    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
-    const int m0 = mtile * BM, n0 = ntile * BN;
-    const int Ntot = g.nseg * g.nsegs;
-    const int seg = n0 / g.nseg;
-    const int nbase = n0 - seg * g.nseg;
-    const int ktiles = (g.K + 31) >> 5;
-    const unsigned short* const wsp = g.wsplit;
-    const long plane = (long)Ntot * g.K;
-
-    float4 ra[A_PER_T];
-    uint4 rb[B_PER_T];
-    auto load_tiles = [&](int kt) {
-#pragma unroll
-        for (int u = 0; u < A_PER_T; ++u) {
-            const int i = tid + u * 256;
-            const int r = i >> 3, c4 = i & 7;
-            const int gm = m0 + r, k = kt * 32 + c4 * 4;
-            ra[u] = (gm < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.a0 + (long)gm * g.lda0 + k) : f4_zero();
-        }
-#pragma unroll
-        for (int u = 0; u < B_PER_T; ++u) {
-            const int i = tid + u * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i < B_PIECES) {
-                const int p = i / (BN * 4), rem = i - p * (BN * 4);
-                const int r = rem >> 2, kg = rem & 3;
-                const int k = kt * 32 + kg * 8;
-                if (nbase + r < g.nseg && n0 + r < Ntot && k < g.K)
-                    v = *reinterpret_cast<const uint4*>(wsp + p * plane + (long)(n0 + r) * g.K + k);
-            }
-            rb[u] = v;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int u = 0; u < A_PER_T; ++u) {
-            const int i = tid + u * 256;
-            const int r = i >> 3, c4 = i & 7;
-            const int kg = c4 >> 1, half = c4 & 1;
-            const Split3f s0 = split3f(ra[u].x), s1 = split3f(ra[u].y), s2 = split3f(ra[u].z), s3 = split3f(ra[u].w);
-            const int slot = (kg * BM + (r ^ kg)) * 2 + half;            // uint2 slots
-            reinterpret_cast<uint2*>(As[0])[slot] = make_uint2(pack_hi16(s0.a, s1.a), pack_hi16(s2.a, s3.a));
-            reinterpret_cast<uint2*>(As[1])[slot] = make_uint2(pack_hi16(s0.b, s1.b), pack_hi16(s2.b, s3.b));
-            reinterpret_cast<uint2*>(As[2])[slot] = make_uint2(pack_hi16(s0.c, s1.c), pack_hi16(s2.c, s3.c));
-        }
-#pragma unroll
-        for (int u = 0; u < B_PER_T; ++u) {
-            const int i = tid + u * 256;
-            if (i < B_PIECES) {
-                const int p = i / (BN * 4), rem = i - p * (BN * 4);
-                const int r = rem >> 2, kg = rem & 3;
-                Bs[p][kg * BN + (r ^ kg)] = rb[u];
-            }
-        }
-    };
-
-    v4f acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const bool more = kt + 1 < ktiles;
-        if (more) load_tiles(kt + 1);
-        {
-            const int kg = lane >> 4, lr = lane & 15;
-            bf16x8 af[3][MT];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    af[p][mt] = __builtin_bit_cast(bf16x8, As[p][kg * BM + ((wm * (MT * 16) + mt * 16 + lr) ^ kg)]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int slot = kg * BN + ((nt * 16 + lr) ^ kg);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bs[0][slot]);
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bs[1][slot]);
-                const bf16x8 b3 = __builtin_bit_cast(bf16x8, Bs[2][slot]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    v4f c = acc[mt][nt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][mt], b1, c, 0, 0, 0);   // x3 w1
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b2, c, 0, 0, 0);   // x2 w2
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b3, c, 0, 0, 0);   // x1 w3
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b1, c, 0, 0, 0);   // x2 w1
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b2, c, 0, 0, 0);   // x1 w2
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b1, c, 0, 0, 0);   // x1 w1
-                    acc[mt][nt] = c;
-                }
-            }
-        }
-        __syncthreads();
-        if (more) {
-            store_tiles();
-            __syncthreads();
-        }
-    }
-
-    const float* const radd = seg == g.radd_seg ? g.radd : nullptr;
-    long rrow[MT][4];                       // row of radd for each of this lane's 8 output rows (one division each)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
-            rrow[mt][r] = radd ? (long)(gm / g.rows_per_b) * g.nseg : 0;
-        }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int nn = nbase + nt * 16 + (lane & 15);
-            if (nn >= g.nseg) continue;
-            const float* bp = g.bias[seg];
-            float* yp = g.y[seg];
-            const float bv = bp ? bp[nn] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
-                if (gm >= g.M) continue;
-                float v = acc[mt][nt][r] + bv;
-                if (radd) v = radd[rrow[mt][r] + nn] + v;
-                if (g.epi == EPI_RELU_RES) v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
-                yp[(long)gm * g.ldy + nn] = v;
-            }
-        }
-    }
-}
-
-// 1b'. The same arithmetic with the A operand kept out of LDS.  The four waves are stacked along M, so a
-// wave is the only reader of its rows of A: each lane loads the 8 consecutive k of "its" row (row l&15, k group
-// l>>4 — exactly the 16x16x32 A-fragment layout) straight from global memory as two float4, splits them in
-// registers and feeds the MFMAs.  Only the (shared) weight planes go through LDS, double-buffered, one barrier
-// per K tile.  LDS traffic per K tile drops from 123 KB to 75 KB per workgroup (MT=2), which was the co-limiter
-// of the MFMA pipe (PMC: LDS busy ~ MFMA busy in the version above).
-template <int MT, int BN>
-__global__ void __launch_bounds__(256) gemm_bf16x6d_kernel(const GemmArgs g) {
-    constexpr int BM = MT * 64;
-    constexpr int NT = BN / 16;
-    constexpr int B_PIECES = 3 * BN * 4;     // 16-byte bf16 pieces of the three B planes
-    constexpr int B_PER_T = (B_PIECES + 255) / 256;
-    __shared__ uint4 Bs[2][3][4 * BN];
-
-    const int total = g.mtiles * g.ntiles;
-    const int chunk = (total + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (tile >= total) return;
-    const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
-
-    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
-    const int kg = lane >> 4, lr = lane & 15;
-    const int m0 = mtile * BM, n0 = ntile * BN;
-    const int Ntot = g.nseg * g.nsegs;
-    const int seg = n0 / g.nseg;
-    const int nbase = n0 - seg * g.nseg;
-    const int ktiles = (g.K + 31) >> 5;
-    const unsigned short* const wsp = g.wsplit;
-    const long plane = (long)Ntot * g.K;
-
-    const float* arow[MT];                   // this lane's A rows (clamped: rows >= M are never stored)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int gm = m0 + wm * (MT * 16) + mt * 16 + lr;
-        gm = gm < g.M ? gm : g.M - 1;
-        arow[mt] = g.a0 + (long)gm * g.lda0 + kg * 8;
-    }
-    float4 ra[MT][2];
-    uint4 rb[B_PER_T];
-    auto load_tiles = [&](int kt) {
-        const bool kin = kt * 32 + kg * 8 < g.K;             // K % 8 == 0: an 8-group is all in or all out
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float4* src = reinterpret_cast<const float4*>(arow[mt] + kt * 32);
-            ra[mt][0] = kin ? src[0] : f4_zero();
-            ra[mt][1] = kin ? src[1] : f4_zero();
-        }
-#pragma unroll
-        for (int u = 0; u < B_PER_T; ++u) {
-            const int i = tid + u * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i < B_PIECES) {
-                const int p = i / (BN * 4), rem = i - p * (BN * 4);
-                const int r = rem >> 2, kq = rem & 3;
-                const int k = kt * 32 + kq * 8;
-                if (nbase + r < g.nseg && n0 + r < Ntot && k < g.K)
-                    v = *reinterpret_cast<const uint4*>(wsp + p * plane + (long)(n0 + r) * g.K + k);
-            }
-            rb[u] = v;
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < B_PER_T; ++u) {
-            const int i = tid + u * 256;
-            if (i < B_PIECES) {
-                const int p = i / (BN * 4), rem = i - p * (BN * 4);
-                const int r = rem >> 2, kq = rem & 3;
-                Bs[buf][p][kq * BN + (r ^ kq)] = rb[u];
-            }
-        }
-    };
-    bf16x8 af[3][MT];
-    auto split_a = [&]() {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const Split3f s0 = split3f(ra[mt][0].x), s1 = split3f(ra[mt][0].y), s2 = split3f(ra[mt][0].z), s3 = split3f(ra[mt][0].w);
-            const Split3f s4 = split3f(ra[mt][1].x), s5 = split3f(ra[mt][1].y), s6 = split3f(ra[mt][1].z), s7 = split3f(ra[mt][1].w);
-            af[0][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.a, s1.a), pack_hi16(s2.a, s3.a), pack_hi16(s4.a, s5.a), pack_hi16(s6.a, s7.a)));
-            af[1][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.b, s1.b), pack_hi16(s2.b, s3.b), pack_hi16(s4.b, s5.b), pack_hi16(s6.b, s7.b)));
-            af[2][mt] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s0.c, s1.c), pack_hi16(s2.c, s3.c), pack_hi16(s4.c, s5.c), pack_hi16(s6.c, s7.c)));
-        }
-    };
-
-    v4f acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    load_tiles(0);
-    store_b(0);
-    split_a();
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ktiles;
-        if (more) load_tiles(kt + 1);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int slot = kg * BN + ((nt * 16 + lr) ^ kg);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bs[buf][0][slot]);
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bs[buf][1][slot]);
-            const bf16x8 b3 = __builtin_bit_cast(bf16x8, Bs[buf][2][slot]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                v4f c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][mt], b1, c, 0, 0, 0);   // x3 w1
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b2, c, 0, 0, 0);   // x2 w2
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b3, c, 0, 0, 0);   // x1 w3
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], b1, c, 0, 0, 0);   // x2 w1
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b2, c, 0, 0, 0);   // x1 w2
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], b1, c, 0, 0, 0);   // x1 w1
-                acc[mt][nt] = c;
-            }
-        }
-        if (more) {
-            store_b(buf ^ 1);
-            split_a();
-        }
-        __syncthreads();
-    }
-
-    const float* const radd = seg == g.radd_seg ? g.radd : nullptr;
-    long rrow[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
-            rrow[mt][r] = radd ? (long)(gm / g.rows_per_b) * g.nseg : 0;
-        }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int nn = nbase + nt * 16 + (lane & 15);
-            if (nn >= g.nseg) continue;
-            const float* bp = g.bias[seg];
-            float* yp = g.y[seg];
-            const float bv = bp ? bp[nn] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wm * (MT * 16) + mt * 16 + (lane >> 4) * 4 + r;
-                if (gm >= g.M) continue;
-                float v = acc[mt][nt][r] + bv;
-                if (radd) v = radd[rrow[mt][r] + nn] + v;
-                if (g.epi == EPI_RELU_RES) v = fmaxf(v, 0.f) + g.e0[(long)gm * g.lde0 + nn];
-                yp[(long)gm * g.ldy + nn] = v;
-            }
-        }
-    }
-}
-
-// 1b''. Strip-mined version.  PMC on the kernel above: 3.8 non-MFMA vector instructions per MFMA (the
-// operand split is 88 per K tile and wave, address arithmetic and bounds checks as much again), while a
-// 16-cycle MFMA leaves room for two — the vector pipe, not the matrix pipe, set the pace.  So:
-//  * one wave keeps its 32 rows of A for THREE 80-column strips of the weights (wave tile 32 x 240, 120
-//    accumulator registers): the split is paid once per 180 MFMAs instead of once per 60;
-//  * the weights are pre-arranged (split_weights_tiled_kernel) as ready-made LDS images, one per (80-column
-//    strip, K tile): [plane][k group][row] 16-byte slots, K zero-padded to 32.  A strip image is 15 KB and
-//    goes global -> LDS by LDS-DMA (no registers, no address arithmetic, no bounds checks), double-buffered:
-//    the image of step j+1 is in flight while step j's 60 MFMAs run; one s_waitcnt + one s_barrier per step;
-//  * the A rows of the next K tile are loaded at strip 0 and split in the shadow of strips 1 and 2.
-// Tiles may span weight segments (the epilogue picks bias/output per strip; segments are multiples of 80).
+// Kernel design (what the counters asked for: a first version with 128x80 tiles and register-staged operands
+// spent 3.8 non-MFMA vector instructions per MFMA — operand split, address arithmetic, bounds checks — while a
+// 16-cycle MFMA leaves issue room for two; its dword epilogue cost another third of the run time):
+//  * the four waves of a workgroup are stacked along M; a wave keeps its 32 rows of A for THREE 80-column
+//    strips of the weights (wave tile 32 x 240, 120 accumulator registers), so the split is paid once per
+//    180 MFMAs;
+//  * the split weights are stored as ready-made LDS images, one per (80-column strip, 32-deep K tile):
+//    [plane][k group][row] 16-byte slots, K zero-padded to 32.  An image is 15 KB and goes global -> LDS by
+//    LDS-DMA (no registers, no address arithmetic, no bounds checks) into a ring of three: two images are in
+//    flight behind the one the 60 MFMAs of a step read; the fp32 A tile (128 x 32) takes the same road once
+//    per K tile and is split from LDS in the shadow of strips 1 and 2.  Every global read being a DMA, the
+//    vector-memory queue is counted by hand: one "s_waitcnt vmcnt(4)" + one s_barrier per step;
+//  * the weights are the MFMA's ROW operand and the activations its COLUMN operand, so a lane ends with four
+//    consecutive output columns of one row: float4 bias/residual loads and float4 stores;
+//  * tiles may span weight segments (bias/output picked per strip; segments are multiples of 80 columns).
+// Measured (M=68 608, N=1 200, K=400): 373 us = 177 TFLOP/s fp32-equivalent = 1.06 PFLOP/s bf16; the 128x80
+// version ran 467 us, the exact fp32-MFMA kernel (single segment) 770 us, rocBLAS fp32 addmm 680 us.
 constexpr int WS_SLOTS = 960;            // 16-byte slots of one strip image: 3 planes x 4 k groups x 80 rows
 
 __global__ void __launch_bounds__(256) split_weights_tiled_kernel(const float* w0, const float* w1, const float* w2,
@@ -802,19 +488,19 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
             // queue, oldest first: image(step) | A tile requested a step ago | image(step+1): only the last may stay in flight
             if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();        // landed for every wave; image(step-1) and the old A tile are free
+            __builtin_amdgcn_s_barrier();                          // landed for every wave; image(step-1) and the old A tile are free
             if (NSUB == 1) {
                 if (kt > 0) { split_mt(0, kt & 1, af); split_mt(1, kt & 1, af); }    // requested a step ago, into the other buffer
-                if (more && !(g.dbg & 1)) issue_a(kt + 1, (kt + 1) & 1);
-            } else if (s == 0 && more && !(g.dbg & 1)) {
+                if (more) issue_a(kt + 1, (kt + 1) & 1);
+            } else if (s == 0 && more) {
                 issue_a(kt + 1, 0);                                // read at strip 1, after the next barrier
             }
-            if (step + 2 < nsteps && !(g.dbg & 1)) issue_b(step + 2);
+            if (step + 2 < nsteps) issue_b(step + 2);
             const uint4* Bi = Bs[buf];
             const int lslot = kg * 80 + lr;
             bf16x8 bq[2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[0][p] = __builtin_bit_cast(bf16x8, Bi[p * 320 + ((g.dbg & 16) ? 0 : lslot)]);
+            for (int p = 0; p < 3; ++p) bq[0][p] = __builtin_bit_cast(bf16x8, Bi[p * 320 + lslot]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt + 1 < NT) {
@@ -823,7 +509,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
                 }
                 const bf16x8 b1 = bq[nt & 1][0], b2 = bq[nt & 1][1], b3 = bq[nt & 1][2];
                 v4f c0 = acc[s][0][nt], c1 = acc[s][1][nt];
-                if (!(g.dbg & 4)) {
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[2][0], c0, 0, 0, 0);   // x3 w1
                 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[2][1], c1, 0, 0, 0);
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[1][0], c0, 0, 0, 0);   // x2 w2
@@ -836,7 +521,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
                 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[0][1], c1, 0, 0, 0);
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[0][0], c0, 0, 0, 0);   // x1 w1
                 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[0][1], c1, 0, 0, 0);
-                } else { c0[0] += (float)b1[0] + (float)b2[1] + (float)b3[2] + (float)af[0][0][0]; c1[1] += (float)af[1][1][1] + (float)af[2][0][1]; }
                 acc[s][0][nt] = c0; acc[s][1][nt] = c1;
                 if (NSUB > 1 && more) {      // the next K tile's rows landed at this step's wait (requested at strip 0)
                     if (s == 1 && nt == 1) split_mt(0, 0, afn);
@@ -852,17 +536,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
         }
     }
 
-    if (g.dbg & 32) {
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) sum += acc[s][mt][nt][0] + acc[s][mt][nt][1] + acc[s][mt][nt][2] + acc[s][mt][nt][3];
-        g.y[0][(long)(m0 + wm * 32 + lr) * g.ldy + kg] = sum;
-        return;
-    }
     // The weights are the MFMA's row operand, the activations its column operand, so a lane ends up with four
     // CONSECUTIVE output columns (4*kg .. 4*kg+3 of each 16-column block) of one row (lr): float4 bias / residual
     // loads and float4 stores, a quarter of the instructions of the row-major accumulator layout.
@@ -891,7 +564,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
                     const float4 x = *reinterpret_cast<const float4*>(erow + nn);
                     v = make_float4(fmaxf(v.x, 0.f) + x.x, fmaxf(v.y, 0.f) + x.y, fmaxf(v.z, 0.f) + x.z, fmaxf(v.w, 0.f) + x.w);
                 }
-                if (!(g.dbg & 8) || v.x == 12345.678f) *reinterpret_cast<float4*>(yrow + nn) = v;
+                *reinterpret_cast<float4*>(yrow + nn) = v;
             }
         }
     }
@@ -1012,11 +685,6 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
     }
 }
 
-static int gemm_variant() {      // development switch; 3 = strip-mined kernel (wide tiles always), 4 = wide only when the grid is large
-    static const int v = getenv("DIGAT_GEMM_V") ? atoi(getenv("DIGAT_GEMM_V")) : 3;
-    return v;
-}
-
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
     const int Ntot = g.nseg * g.nsegs;
@@ -1049,35 +717,14 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
     ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.K >= 32 && g.ldy % 4 == 0 && g.lde0 % 4 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
         g.k0 == g.K && !g.transW) {
-        const int variant = gemm_variant();
-        { static const int dbg = getenv("DIGAT_GEMM_DBG") ? atoi(getenv("DIGAT_GEMM_DBG")) : 0; g.dbg = dbg; }
-        if (variant >= 3) {
-            const int strips = Ntot / 80;
-            g.mtiles = (g.M + 127) / 128;
-            const bool wide = strips % 3 == 0 && (variant == 3 || (long)g.mtiles * (strips / 3) >= 512);
-            if (wide) {
-                g.ntiles = strips / 3;
-                hipLaunchKernelGGL((gemm_bf16x6s_kernel<3>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
-            } else {
-                g.ntiles = strips;
-                hipLaunchKernelGGL((gemm_bf16x6s_kernel<1>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
-            }
-            DIGAT_CHECK_LAUNCH();
-            return DIGAT_OK;
-        }
-        g.ntiles = (Ntot + 79) / 80;
-        if (variant == 0) {
-            g.mtiles = (g.M + 127) / 128;
-            hipLaunchKernelGGL((gemm_bf16x6_kernel<128, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
-                               0, st, g);
-        } else if (variant == 1) {
-            g.mtiles = (g.M + 127) / 128;
-            hipLaunchKernelGGL((gemm_bf16x6d_kernel<2, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
-                               0, st, g);
+        const int strips = Ntot / 80;
+        g.mtiles = (g.M + 127) / 128;
+        if (strips % 3 == 0) {           // 240-column tiles: the operand split is paid once per three strips
+            g.ntiles = strips / 3;
+            hipLaunchKernelGGL((gemm_bf16x6s_kernel<3>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
         } else {
-            g.mtiles = (g.M + 255) / 256;
-            hipLaunchKernelGGL((gemm_bf16x6d_kernel<4, 80>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256),
-                               0, st, g);
+            g.ntiles = strips;
+            hipLaunchKernelGGL((gemm_bf16x6s_kernel<1>), dim3((unsigned)(((g.mtiles * g.ntiles + 7) / 8) * 8)), dim3(256), 0, st, g);
         }
         DIGAT_CHECK_LAUNCH();
         return DIGAT_OK;
@@ -2031,17 +1678,14 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
 
 // ---- bf16x6 weight preparation + a directly callable linear (tests, micro-benchmarks) --------------
 size_t digat_split_weights_bytes(int rows, int K) {
-    const size_t tiled = (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;
-    const size_t planes = (size_t)3 * rows * K * 2;
-    return tiled > planes ? tiled : planes;
+    return (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;       // one 15 KB image per (80-row strip, K tile)
 }
 
 static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st) {
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    if (gemm_variant() >= 3) hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
-    else hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
+    hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
