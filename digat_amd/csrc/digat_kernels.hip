@@ -1836,11 +1836,35 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // Inference fast path with folded attention queries (digat_fold_attention): per layer the [B,d]
 // linears shrink from 9 launches to 4 — {topic query, user query, next layer's K3 of the user graph}
 // all read the same c_n and go out as ONE three-segment launch.
+// Within a layer the news-graph update and the user-graph update read only the PREVIOUS contexts
+// (graphEncoders.py:194-195), so the news chain — K3, projection, score, aggregation, context pooling, gate, and
+// the queries derived from the new c_n — is independent of the user graph's Eq. 8 until the user context is
+// pooled.  The news kernels are small (N = 10 nodes, [B,d] linears: tens of workgroups, latency chains) and run
+// on a side stream under the user graph's projection / score / aggregation, which fill the chip; fork and join
+// are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
+// caller's stream.
+struct SideStream { hipStream_t s; hipEvent_t fork, join; int ok; };
+static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
+static SideStream* side_stream() {
+    static SideStream tab[16];
+    static int state[16];                    // 0 = untried, 1 = ready, -1 = unavailable
+    int dev = 0;
+    if (!g_side_stream_on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (state[dev] == 0) {                   // one process per GPU; a race here would only create a spare stream
+        SideStream& x = tab[dev];
+        const bool ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1 ? &tab[dev] : nullptr;
+}
+
 static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                               const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
-                              void* xws, void* cws, float* kq_t, float* kq_u, float* r_user, float* r_news,
-                              hipStream_t st, const int* row_group, int G, const float* ue_groups) {
+                              void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
+                              float* r_news, hipStream_t st, const int* row_group, int G, const float* ue_groups) {
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
@@ -1848,15 +1872,15 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     float* glob = (float*)((char*)cws + 2 * s2);  // [B,d]; cws holds >= 2*s2 + 2*[B,d] (user-context layout)
     int rc;
     // the user-side queries + (optionally) the next user-graph K3, all from c_n
-    auto from_c_n = [&](int next_layer) -> int {
+    auto from_c_n = [&](int next_layer, hipStream_t sq) -> int {
         GemmArgs g = gemm_plain(c_n, d, p->user_news_fold_W, p->user_news_fold_b, kq_t, d, B, d, d, 0);
         g.w[1] = p->userAtt_fold_W; g.bias[1] = p->userAtt_fold_b; g.y[1] = kq_u;
         g.nsegs = 2;
         if (next_layer < L) {
-            g.w[2] = p->user[next_layer].F3; g.bias[2] = p->user[next_layer].b3; g.y[2] = r_user;
+            g.w[2] = p->user[next_layer].F3; g.bias[2] = p->user[next_layer].b3; g.y[2] = r_user2[next_layer & 1];
             g.nsegs = 3;
         }
-        return launch_gemm(g, st);
+        return launch_gemm(g, sq);
     };
     auto user_ctx_tail = [&](const float* Xu_cur, const float* addend) -> int {
         int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, st);
@@ -1868,20 +1892,21 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (e) return e;
         return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, st);
     };
-    auto news_ctx = [&](const float* Xn_cur) -> int {
+    auto news_ctx = [&](const float* Xn_cur, hipStream_t sq) -> int {
         const long ldx = (long)N * d;
-        float* kq = kq_t;                          // free here: the user side has consumed it
-        int e = launch_gemm(gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0), st);
+        float* kq = kq_t;                          // free here: the previous user context has consumed it
+        int e = launch_gemm(gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0), sq);
         if (e) return e;
-        e = launch_pool(Xn_cur, ldx, kq, Mn, nullptr, glob, B, N, d, st);
+        e = launch_pool(Xn_cur, ldx, kq, Mn, nullptr, glob, B, N, d, sq);
         if (e) return e;
         GemmArgs g = gemm_plain(Xn_cur, ldx, p->news_graph_W, p->news_graph_b, c_n, d, B, d, 2 * d, 0);
         g.k0 = d; g.a1 = glob; g.lda1 = d;
         g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = c_n; g.lde2 = d;
-        return launch_gemm(g, st);
+        return launch_gemm(g, sq);
     };
 
-    rc = from_c_n(0);
+    SideStream* side = side_stream();
+    rc = from_c_n(0, st);
     if (rc) return rc;
     rc = user_ctx_tail(Xu[0], nullptr);            // c_u (:192)
     if (rc) return rc;
@@ -1890,10 +1915,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     for (int i = 0; i < L; ++i) {
         const digat_layer_params& ln = p->news[i];
         const digat_layer_params& lu = p->user[i];
-        rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), st);     // K3 of the news graph
-        if (rc) return rc;
-        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit);
-        if (rc) return rc;
+        const float* r_user = r_user2[i & 1];     // K3 of the user graph, from the previous c_n
+        hipStream_t sn = side ? side->s : st;
+        if (side) {
+            if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(sn, side->fork, 0) != hipSuccess)
+                return DIGAT_ERR_LAUNCH;
+        }
+        // ---- user graph, Eq. 8 (caller's stream)
         if (i == 0 && row_group) {
             // layer 0 of grouped rows: every row of a group has the same user nodes, so project the G groups
             // once ([G*U] rows instead of [B*U]) and expand h | P' = r + P | Q per row
@@ -1940,11 +1968,20 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
         }
         if (rc) return rc;
+        // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
+        rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
+        if (rc) return rc;
+        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
+        if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
-        rc = news_ctx(xn_cur);                     // c_n += ... (:196)
+        rc = news_ctx(xn_cur, sn);                 // c_n += ... (:196)
         if (rc) return rc;
-        rc = from_c_n(i + 1);                      // queries (+ next K3) from the UPDATED c_n
+        rc = from_c_n(i + 1, sn);                  // queries (+ next K3, into the other r_user buffer) from the UPDATED c_n
         if (rc) return rc;
+        if (side) {
+            if (hipEventRecord(side->join, sn) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
+                return DIGAT_ERR_LAUNCH;
+        }
         rc = user_ctx_tail(Xu[un], c_u);           // c_u += ... (:197)
         if (rc) return rc;
     }
@@ -1960,7 +1997,8 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += 2 * align_up((size_t)B * N * d * 4, 256);     // news nodes, ping-pong
     tot += digat_xattn_workspace_bytes(B, nmax, d);
     tot += max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
-    tot += 4 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user, r_news
+    tot += 5 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user x2, r_news
+    tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
     return tot;
 }
 
@@ -1999,6 +2037,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     float* kq_u = (float*)(ws + sb);
     float* r_user = (float*)(ws + 2 * sb);
     float* r_news = (float*)(ws + 3 * sb);
+    float* const r_user2[2] = {r_user, (float*)(ws + 4 * sb)};
+    void* xws_news = ws + 5 * sb;
 
     int rc;
     // user graph nodes = [history | topic nodes]  (:191)
@@ -2022,7 +2062,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  cws, kq_t, kq_u, r_user, r_news, st, row_group, G, ue);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, st, row_group, G, ue);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -2054,6 +2094,12 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         if (rc) return rc;
     }
     return DIGAT_OK;
+}
+
+int digat_set_side_stream(int enabled) {
+    const int prev = g_side_stream_on;
+    g_side_stream_on = enabled ? 1 : 0;
+    return prev;
 }
 
 int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,

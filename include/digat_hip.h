@@ -164,6 +164,12 @@ int digat_encoder_fwd(const digat_params* params,
                       int B, int N, int H,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* digat_encoder_fwd / _grouped run the news-graph kernels of a layer (small: N nodes, [B,d] linears) on an
+ * internal side stream under the user graph's Eq. 8 and join before the user context is pooled (two events per
+ * layer; capturable).  0 keeps every launch on the caller's stream (also: env DIGAT_SINGLE_STREAM=1).  Returns
+ * the previous setting.  Results do not depend on it. */
+int digat_set_side_stream(int enabled);
+
 /* The same inference for rows that SHARE users: in dev/test scoring the ~37 candidate rows of one
  * impression carry identical user tensors (util.py:57-67 expands them per row).  Here the user side is
  * passed once per group — user_news_embedding [G,H,d], user_graph [G,U,U], user_category_mask [G,C+1],

@@ -314,3 +314,31 @@ def test_grouped_inference_is_bit_identical_to_per_row():
     a = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
     b = util.score_rows(model, dc, 0, dc.rows, 512, grouped=True)
     assert torch.equal(a, b)
+
+
+def test_side_stream_schedule_is_bit_identical_to_single_stream():
+    """The news-graph chain on the side stream (default) vs everything on the caller's stream."""
+    from digat_amd import synthetic, util, _lib
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=120, mean_candidates=30.0,
+                               max_candidates=80, seed=91)
+    corpus = synthetic.make_corpus(spec)
+    L = 3
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=92, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    prev = _lib.lib().digat_set_side_stream(0)
+    try:
+        single = util.score_rows(model, dc, 0, dc.rows, 1024)
+        _lib.lib().digat_set_side_stream(1)
+        for _ in range(3):                   # a race would not reproduce the same bits three times
+            both = util.score_rows(model, dc, 0, dc.rows, 1024)
+            assert torch.equal(single, both)
+    finally:
+        _lib.lib().digat_set_side_stream(prev)
