@@ -183,7 +183,7 @@ def main():
 
     # HBM traffic of the roofline kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass); their per-launch means are kept under profiles/ and quoted here.
-    symbols = {"proj": "gemm_bf16x6s_kernel" if getattr(model.graph_encoder, "projection_mode", "") == "bf16x6"
+    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(model.graph_encoder, "projection_mode", "") == "bf16x6"
                else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_score_kernel", "agg": "xattn_agg_kernel",
                "topic": "topic_pool_kernel", "pool": "attn_pool_kernel"}
 
