@@ -2194,3 +2194,4 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 }  // extern "C"
 
 #include "digat_train.inc"
+#include "digat_eval.inc"

@@ -66,6 +66,39 @@ def scoring(labels: np.ndarray, ranks: np.ndarray, row_impression: np.ndarray) -
     return float(np.mean(aucs)), float(np.mean(mrrs)), float(np.mean(n5)), float(np.mean(n10))
 
 
+def device_ranks_and_metrics(scores, row_impression: np.ndarray, labels: np.ndarray = None):
+    """Ranks (and, with labels, the four metrics) computed on the GPU by ``digat_rank_metrics``.
+
+    ``scores``: a CUDA float32 tensor [R] in impression-major row order; ``row_impression`` / ``labels``: host
+    arrays.  Returns ``(ranks int64 numpy [R], (auc, mrr, ndcg5, ndcg10) or None)`` — the same values as
+    ``impression_ranks`` + ``scoring`` (ranks identical; metrics equal to float64 rounding)."""
+    import torch
+    from . import _lib
+    imp = np.asarray(row_impression, dtype=np.int64)
+    R = len(imp)
+    dev = _lib.require_device(scores)
+    if R == 0:
+        return np.zeros(0, dtype=np.int64), None
+    if np.any(np.diff(imp) < 0):
+        raise ValueError("rows must be impression-major")
+    starts = np.r_[0, np.flatnonzero(np.diff(imp)) + 1, R].astype(np.int64)
+    I = len(starts) - 1
+    sc = scores.detach().to(torch.float32).contiguous()
+    st = torch.from_numpy(starts).to(dev)
+    ranks = torch.empty(R, dtype=torch.int32, device=dev)
+    lab = per = mean = None
+    if labels is not None:
+        lab = torch.from_numpy(np.ascontiguousarray(np.asarray(labels) > 0).view(np.uint8)).to(dev)
+        per = torch.empty((I, 4), dtype=torch.float64, device=dev)
+        mean = torch.empty(4, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().digat_rank_metrics(sc.data_ptr(), lab.data_ptr() if lab is not None else None, st.data_ptr(), I,
+                                             ranks.data_ptr(), per.data_ptr() if per is not None else None,
+                                             mean.data_ptr() if mean is not None else None, _lib.stream_ptr()),
+               "digat_rank_metrics")
+    metrics = tuple(float(v) for v in mean.cpu().numpy()) if mean is not None else None
+    return ranks.cpu().numpy().astype(np.int64), metrics
+
+
 class AvgMetric:
     """util.py:100-121: the model-selection average."""
 

@@ -173,9 +173,12 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
     scores_np = scores.detach().cpu().numpy()
     if rank != 0:
         return scores_np, None
-    ranks = evaluate.impression_ranks(scores_np, row_imp)
+    if scores.is_cuda:          # ranking + metrics on the device (digat_rank_metrics); one wave per impression
+        ranks, metrics = evaluate.device_ranks_and_metrics(scores, row_imp, labels)
+    else:                       # host tensors only occur in the CPU harness tests (score_fn)
+        ranks = evaluate.impression_ranks(scores_np, row_imp)
+        metrics = evaluate.scoring(labels, ranks, row_imp) if labels is not None else None
     if result_file is not None:
         with open(result_file, "w", encoding="utf-8") as f:
             f.write("\n".join(evaluate.rank_lines(ranks, row_imp)))
-    metrics = evaluate.scoring(labels, ranks, row_imp) if labels is not None else None
     return scores_np, metrics

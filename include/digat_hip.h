@@ -231,6 +231,16 @@ int digat_xattn_pairwise_bwd(const float* dOut, const float* out, const float* X
                              void* stream);
 int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* stream);          /* dr[b] = sum_j dP[b,j] */
 
+/* ---- H2: ranking + metrics of the dev/test driver  (util.py:70-80, evaluate.py:32-89) -------------------
+ * scores [R] f32 in impression-major row order; impression_start [I+1] int64 (row offsets; impression i owns
+ * rows [start[i], start[i+1])).  ranks [R] int32 receives the 1-based rank of every candidate after a STABLE
+ * descending sort of its impression's scores (what util.py:73-79 writes to the rank file).  With labels [R]
+ * (bytes, non-zero = clicked) and per_impression [I,4] f64 it also writes AUC, MRR, nDCG@5, nDCG@10 of every
+ * impression on 1/rank scores (evaluate.py:45-60), and with mean4 [4] their means over the I impressions
+ * (evaluate.py:85-89).  labels / per_impression / mean4 may be NULL (ranks only). */
+int digat_rank_metrics(const float* scores, const uint8_t* labels, const int64_t* impression_start, int num_impressions,
+                       int32_t* ranks, double* per_impression, double* mean4, void* stream);
+
 /* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
  * Between start and stop every kernel launch of this library is bracketed by two events recorded
  * on the stream it is launched on.  stop() synchronises and returns, per kernel kind, the summed

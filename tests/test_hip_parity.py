@@ -342,3 +342,27 @@ def test_side_stream_schedule_is_bit_identical_to_single_stream():
             assert torch.equal(single, both)
     finally:
         _lib.lib().digat_set_side_stream(prev)
+
+
+@pytest.mark.parametrize("seed,impressions,max_c,quant", [(1, 300, 40, 0), (2, 50, 300, 8), (3, 1, 2, 0), (4, 2000, 60, 4)])
+def test_device_ranks_and_metrics_match_host(seed, impressions, max_c, quant):
+    """digat_rank_metrics vs evaluate.impression_ranks / evaluate.scoring (ties included: quantised scores)."""
+    from digat_amd import evaluate
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(2, max_c + 1, size=impressions)
+    imp = np.repeat(np.arange(impressions), counts)
+    scores = rng.standard_normal(len(imp)).astype(np.float32)
+    if quant:
+        scores = np.round(scores * quant) / quant          # many exact ties: the stable order decides
+    labels = np.zeros(len(imp), dtype=np.int64)
+    starts = np.r_[0, np.cumsum(counts)]
+    for s, e in zip(starts[:-1], starts[1:]):               # at least one positive and one negative
+        k = rng.integers(1, max(2, min(4, e - s)))
+        labels[s + rng.choice(e - s, size=min(k, e - s - 1), replace=False)] = 1
+    want_r = evaluate.impression_ranks(scores, imp)
+    want_m = evaluate.scoring(labels, want_r, imp)
+    got_r, got_m = evaluate.device_ranks_and_metrics(torch.from_numpy(scores).to(_dev()), imp, labels)
+    assert np.array_equal(got_r, want_r)
+    assert np.allclose(got_m, want_m, rtol=0, atol=1e-12), (got_m, want_m)
+    only_r, none_m = evaluate.device_ranks_and_metrics(torch.from_numpy(scores).to(_dev()), imp)
+    assert np.array_equal(only_r, want_r) and none_m is None
