@@ -1514,6 +1514,115 @@ __global__ void __launch_bounds__(1024) topic_pool_kernel(const TopicArgs g) {
     }
 }
 
+// H <= 64 (the reference's max_history_num is 50): the history rows are read ONCE.  A wave owns 64 channels and
+// keeps its slice of every history row in registers, in the MFMA operand layout of phase 3 (lane (lr, lq) holds
+// channels c0+4lr..+3 of rows 4*step+lq): all 16 loads of a lane are in flight together, the scores are
+// partial dot products over the wave's channels (reduced over the 16 lr lanes, then over the waves through LDS),
+// the segment softmax is one masked wave reduction per category, and the MFMAs take X straight from the
+// registers.  Same results as the kernel above up to the summation order of the scores.
+constexpr int TOPIC_RES_STEPS = 16;      // 4-row steps held in registers
+
+__global__ void __launch_bounds__(1024) topic_pool_resident_kernel(const TopicArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = g.H, hs = H | 1;
+    const int ct = (g.C1 + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nw = nthreads >> 6;
+    float* M = reinterpret_cast<float*>(smem);               // [ct*16][hs]
+    float* part = M + ct * 16 * hs;                          // [nw][64] partial scores
+    float* sa = part + nw * 64;                              // [64]
+    int* sidx = reinterpret_cast<int*>(sa + 64);             // [64]
+    const int b = blockIdx.x;
+    const float* Xb = g.Xu + (long)b * g.ld_b;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ch = wave * 64 + 4 * lr;
+    const bool ch_ok = ch < g.d;             // no early exit: the MFMAs need every lane's operand rows
+    const int nsteps = (H + 3) >> 2;
+
+    float4 xq[TOPIC_RES_STEPS];
+#pragma unroll
+    for (int s = 0; s < TOPIC_RES_STEPS; ++s) {
+        const int j = s * 4 + lq;
+        xq[s] = (s < nsteps && j < H && ch_ok) ? *reinterpret_cast<const float4*>(Xb + (long)j * g.d + ch) : f4_zero();
+    }
+    const float4 k4 = ch_ok ? *reinterpret_cast<const float4*>(g.kq + (long)b * g.d + ch) : f4_zero();
+    if (tid < 64) {
+        long v = -1;
+        if (tid < H) v = g.idx[(long)b * H + tid];
+        sidx[tid] = (v >= 0 && v < g.C1) ? (int)v : -1;
+    }
+    for (int i = tid; i < ct * 16 * hs; i += nthreads) M[i] = 0.f;
+
+    // partial scores of this wave's 64 channels
+#pragma unroll
+    for (int s = 0; s < TOPIC_RES_STEPS; ++s) {
+        float p = fmaf(xq[s].w, k4.w, fmaf(xq[s].z, k4.z, fmaf(xq[s].y, k4.y, xq[s].x * k4.x)));
+        p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 8, 64);
+        if (lr == 0) part[wave * 64 + s * 4 + lq] = p;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += part[w * 64 + tid];
+        sa[tid] = a / g.sqrt_d;
+    }
+    __syncthreads();
+    // segment softmax: wave w takes the categories c = w, w + nw, ...; lane t is history row t
+    {
+        const int my = lane < H ? sidx[lane] : -2;
+        const float v = lane < H ? sa[lane] : 0.f;
+        for (int c = wave; c < g.C1; c += nw) {
+            const bool in = my == c;
+            const float m = wave_max(in ? v : -INFINITY);
+            const float e = in ? expf(v - m) : 0.f;
+            const float den = wave_sum(e);
+            if (in) {
+                const float al = e / den;
+                M[c * hs + lane] = al;
+                if (g.alpha_out) g.alpha_out[(long)b * H + lane] = al;
+            }
+        }
+        if (wave == 0 && g.alpha_out && lane < H && my < 0) g.alpha_out[(long)b * H + lane] = 0.f;
+    }
+    __syncthreads();
+
+    v4f acc[TOPIC_MAX_CT][4];
+#pragma unroll
+    for (int it = 0; it < TOPIC_MAX_CT; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[it][s] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < TOPIC_RES_STEPS; ++s) {
+        if (s < nsteps) {
+            const int j = s * 4 + lq;
+            const float4 xc = xq[s];
+#pragma unroll
+            for (int it = 0; it < TOPIC_MAX_CT; ++it) {
+                if (it < ct) {
+                    const float av = j < H ? M[(it * 16 + lr) * hs + j] : 0.f;
+                    acc[it][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.x, acc[it][0], 0, 0, 0);
+                    acc[it][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.y, acc[it][1], 0, 0, 0);
+                    acc[it][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.z, acc[it][2], 0, 0, 0);
+                    acc[it][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc.w, acc[it][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* Ob = g.out + (long)b * g.C1 * g.d;
+#pragma unroll
+    for (int it = 0; it < TOPIC_MAX_CT; ++it) {
+        if (it < ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = it * 16 + 4 * lq + r;
+                if (c < g.C1 && ch_ok)
+                    *reinterpret_cast<float4*>(Ob + (long)c * g.d + ch) =
+                        make_float4(acc[it][0][r], acc[it][1][r], acc[it][2][r], acc[it][3][r]);
+            }
+        }
+    }
+}
+
 static int launch_topic_args(TopicArgs g, hipStream_t st) {
     static int skip = -1;
     if (skip < 0) { const char* e = getenv("DIGAT_TOPIC_SKIP"); skip = e ? atoi(e) : 0; }
@@ -1530,7 +1639,12 @@ static int launch_topic_args(TopicArgs g, hipStream_t st) {
             raised = 1;
         }
     }
-    hipLaunchKernelGGL(topic_pool_kernel, dim3(g.B), dim3(64 * groups), lds, st, g);
+    if (g.H <= 64 && !(g.skip & 64)) {
+        const size_t ldsr = ((size_t)ct * 16 * (g.H | 1) + (size_t)groups * 64 + 128) * 4;
+        hipLaunchKernelGGL(topic_pool_resident_kernel, dim3(g.B), dim3(64 * groups), ldsr, st, g);
+    } else {
+        hipLaunchKernelGGL(topic_pool_kernel, dim3(g.B), dim3(64 * groups), lds, st, g);
+    }
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
