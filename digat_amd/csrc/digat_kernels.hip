@@ -36,7 +36,9 @@ static struct {
     hipEvent_t* ev;
     int* kind;
     double* work;
-} g_prof = {0, 0, 0, nullptr, nullptr, nullptr};
+    unsigned long long* rows_dev;      // row-list GEMM launches add the rows they actually processed (device counter)
+    double flops_per_row; int rows_kind; double rows_nominal;
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.0, 0, 0.0};
 
 struct ProfScope {
     hipStream_t st; int slot;
@@ -100,6 +102,8 @@ struct GemmArgs {
     int mtiles, ntiles;
     const unsigned short* wsplit;            // bf16x6 path: [3 planes][nsegs*nseg][K] bf16 of the weights
     const float* radd; int radd_seg, rows_per_b;   // segment radd_seg: y += radd[row / rows_per_b][col]  (K3 + K1 of Eq. 8)
+    unsigned long long* exec_rows;                 // profiling only: += rows processed by a row-list launch
+    const int* rowidx; const int* nrows_dev;       // bf16x6 kernel only: process rows rowidx[0 .. *nrows_dev) of A / y (live rows)
     int m_dispatch;                                // != 0: choose the kernel as if M were this (bit-identical results across batchings)
 };
 
@@ -395,8 +399,13 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
     __shared__ uint4 Bs[RING][WS_SLOTS];
     __shared__ uint4 As[ABUF][1024];         // slot r*8 + (c4 ^ ((r>>1)&7)): conflict-free 32-byte row pieces
 
-    const int total = g.mtiles * g.ntiles;
+    // With a row list (rowidx / *nrows_dev, written on the device) the grid is sized for all M rows and the tile
+    // count comes from the live row count, so the live tiles still spread over the 8 XCDs evenly.
+    const int Mv = g.nrows_dev ? *g.nrows_dev : g.M;
+    if (g.exec_rows && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.exec_rows, (unsigned long long)Mv);
+    const int total = ((Mv + 127) >> 7) * g.ntiles;
     const int chunk = (total + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= chunk) return;
     const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (tile >= total) return;
     const int mtile = tile / g.ntiles, ntile = tile - mtile * g.ntiles;
@@ -432,7 +441,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
         const int sl = (wm + 4 * k) * 64 + lane;
         const int r = sl >> 3, c4 = (sl & 7) ^ ((r >> 1) & 7);
         int gm = m0 + r;
-        gm = gm < g.M ? gm : g.M - 1;                            // rows >= M are never stored
+        gm = gm < Mv ? gm : Mv - 1;                              // rows >= Mv are never stored
+        if (g.rowidx) gm = g.rowidx[gm];
         asrc[k] = g.a0 + (long)gm * g.lda0 + c4 * 4;
         ac4[k] = c4 * 4;
     }
@@ -541,8 +551,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x6s_kernel(const GemmArgs g) 
     // loads and float4 stores, a quarter of the instructions of the row-major accumulator layout.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int gm = m0 + wm * 32 + mt * 16 + lr;
-        if (gm >= g.M) continue;
+        const int gv = m0 + wm * 32 + mt * 16 + lr;
+        if (gv >= Mv) continue;
+        const int gm = g.rowidx ? g.rowidx[gv] : gv;
         const long rb = g.radd ? (long)(gm / g.rows_per_b) * g.nseg : 0;
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
@@ -685,8 +696,16 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const GemmArgs g) {
     }
 }
 
+// the strip-mined bf16x6 kernel serves this launch (the only kernel that takes a row list)
+static bool gemm_is_bf16x6(const GemmArgs& g) {
+    const int Md = g.m_dispatch > 0 ? g.m_dispatch : g.M;
+    return g.wsplit && Md >= 2048 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.K >= 32 && g.ldy % 4 == 0 && g.lde0 % 4 == 0 &&
+           (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) && g.k0 == g.K && !g.transW;
+}
+
 static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEAR) {
     if (g.M <= 0) return DIGAT_OK;
+    if (g.rowidx && !gemm_is_bf16x6(g)) return DIGAT_ERR_ARG;
     const int Ntot = g.nseg * g.nsegs;
     const int Md = g.m_dispatch > 0 ? g.m_dispatch : g.M;
     if (Md < 2048 && g.nseg % 80 == 0 && !g.transW && g.K % 4 == 0 && g.k0 % 16 == 0 && !g.radd) {
@@ -714,7 +733,14 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
         }
         return DIGAT_OK;
     }
-    ProfScope prof(kind, 2.0 * g.M * (double)Ntot * g.K, st);
+    // a row-list launch does the work of its live rows only: the kernel adds that count to a device counter and
+    // digat_profile_stop prices it; the launch itself is recorded with zero work
+    const bool listed = g.rowidx != nullptr;
+    if (listed && g_prof.enabled) {
+        g.exec_rows = g_prof.rows_dev;
+        g_prof.flops_per_row = 2.0 * (double)Ntot * g.K; g_prof.rows_kind = kind; g_prof.rows_nominal += g.M;
+    }
+    ProfScope prof(kind, listed ? 0.0 : 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.K >= 32 && g.ldy % 4 == 0 && g.lde0 % 4 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
         g.k0 == g.K && !g.transW) {
         const int strips = Ntot / 80;
@@ -1675,6 +1701,102 @@ __global__ void __launch_bounds__(256) build_user_nodes_kernel(const float4* ue,
     }
 }
 
+// ---- live user-graph nodes --------------------------------------------------------------------------------
+// A node that has no edge to any other node and whose pooled contribution is masked cannot reach the encoder's
+// outputs: padding slots of the history (MIND_corpus.py:153-156: identity row, category index C, and
+// category_mask[C] is never set) and topic nodes of categories the user never read (identity row, never pooled).
+// About half of the 67 nodes of a MIND-shaped user graph are such nodes.  Their rows are left out of the
+// projections of layers >= 1 (layer 0 computes every row, so the buffers stay finite; a dead node keeps
+// evolving from stale-but-finite values that nothing reads).  Live means:
+//   any off-diagonal entry in the node's adjacency row or column, or
+//   a history slot whose category is unmasked, or any history slot of a row with NO unmasked category (the
+//   context attention is then uniform over all C+1 buckets: util E2, the empty-history user).
+// One wave per row b.  Lane i builds the bit mask of row i of the adjacency (diagonal cleared); a node has an
+// off-diagonal entry in its row iff its mask is non-zero, and in its column iff its bit is set in the OR of all
+// the masks.  flags [B,U] bytes and cnt [B] are written; after the scan, live_list_kernel writes the row indices
+// b*U + i of the live nodes in ascending order.
+__global__ void __launch_bounds__(256) user_live_flags_kernel(const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
+                                                              int B, int U, int H, int C1, uint8_t* flags, int* cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const uint8_t* A = Au + (long)b * U * U;
+    bool any_cat = false;
+    for (int c = lane; c < C1; c += 64) any_cat |= cat_mask[(long)b * C1 + c] != 0;
+    any_cat = __any(any_cat);
+    // U <= DIGAT_MAX_NODES = 128: two nodes per lane, masks of 4 x 32 bits
+    unsigned rm[2][4];
+    unsigned cm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) rm[h][w] = 0u;
+        if (i < U) {
+            const uint8_t* row = A + (long)i * U;
+            for (int j = 0; j < U; ++j)
+                if (row[j] && j != i) rm[h][j >> 5] |= 1u << (j & 31);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cm[w] |= rm[h][w];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cm[w] |= __shfl_xor(cm[w], o, 64);
+    int count = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        bool live = false;
+        if (i < U) {
+            live = (rm[h][0] | rm[h][1] | rm[h][2] | rm[h][3]) != 0u || ((cm[i >> 5] >> (i & 31)) & 1u);
+            if (i < H) {
+                const long c = cat_idx[(long)b * H + i];
+                live |= !any_cat || (c >= 0 && c < C1 && cat_mask[(long)b * C1 + c] != 0);
+            }
+            flags[(long)b * U + i] = live ? 1 : 0;
+        }
+        count += __popcll(__ballot(live));
+    }
+    if (lane == 0) cnt[b] = count;
+}
+
+__global__ void __launch_bounds__(256) live_list_kernel(const uint8_t* flags, const int* off, int B, int U, int* rowidx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    int base = off[b];
+    for (int i0 = 0; i0 < U; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < U && flags[(long)b * U + i] != 0;
+        const unsigned long long m = __ballot(live);
+        if (live) rowidx[base + __popcll(m & ((1ull << lane) - 1ull))] = b * U + i;
+        base += __popcll(m);
+    }
+}
+
+// off[b] = sum of cnt[0..b), off[B] = total: one workgroup, B <= 2^20
+__global__ void __launch_bounds__(1024) exclusive_scan_kernel(const int* cnt, int* off, int B) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int s = tid * per, e = s + per < B ? s + per : B;
+    int a = 0;
+    for (int i = s; i < e; ++i) a += cnt[i];
+    part[tid] = a;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = s; i < e; ++i) { off[i] = run; run += cnt[i]; }
+    if (tid == 1023) off[B] = part[1023];
+}
+
 // out[b] = in[group[b]] for rows of `row_bytes` bytes (16-byte multiple or byte-wise)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const uint8_t* in, uint8_t* out, const int* group, long B, long row_bytes) {
     const long total = B * row_bytes;
@@ -1753,7 +1875,7 @@ int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, co
 static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
-                      const void* wsplit = nullptr) {
+                      const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -1767,6 +1889,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.nsegs = 3;
     g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
     g.radd = r_given; g.radd_seg = 1; g.rows_per_b = n; // P' = K3 + K1: the reference's left-to-right order
+    if (rowidx && gemm_is_bf16x6(g)) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }   // live rows only (see user_live_rows_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
     return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st);
@@ -1958,6 +2081,7 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
 // caller's stream.
 struct SideStream { hipStream_t s; hipEvent_t fork, join; int ok; };
+static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
 static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
 static SideStream* side_stream() {
     static SideStream tab[16];
@@ -1978,7 +2102,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
-                              float* r_news, hipStream_t st, const int* row_group, int G, const float* ue_groups) {
+                              float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups) {
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
@@ -2019,6 +2143,27 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         return launch_gemm(g, sq);
     };
 
+    // live rows of the user graph for the projections of layers >= 1 (DIGAT_NO_SKIP=1: every row)
+    const int* rowidx = nullptr;
+    const int* nrows_dev = nullptr;
+    uint8_t* live_flags = nullptr;
+    auto find_live_rows = [&](hipStream_t sq) -> int {     // needed from layer 1 on: runs beside layer 0
+        int* cnt = live_ws;
+        int* off = cnt + align_up((size_t)B, 64);
+        int* idx = off + align_up((size_t)B + 1, 64);
+        live_flags = (uint8_t*)(idx + align_up((size_t)B * U, 64));
+        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + C1 + H * 8.0) + (double)B * U * 6, sq);
+        hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
+                           live_flags, cnt);
+        DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt, off, B);
+        DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)live_flags, (const int*)off, B, U, idx);
+        DIGAT_CHECK_LAUNCH();
+        rowidx = idx; nrows_dev = off + B;
+        return DIGAT_OK;
+    };
+    const bool want_live = L > 1 && g_live_rows_on && live_ws;
     SideStream* side = side_stream();
     rc = from_c_n(0, st);
     if (rc) return rc;
@@ -2079,10 +2224,16 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             // (expanded) before the pairwise kernels run, and the output is written only by the aggregation
             rc = launch_xattn_pairwise(P, Q, h, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st);
         } else {
-            rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
+            // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
+            rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
+                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr);
         }
         if (rc) return rc;
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
+        if (i == 0 && want_live) {
+            rc = find_live_rows(sn);
+            if (rc) return rc;
+        }
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
         if (rc) return rc;
         rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
@@ -2113,6 +2264,8 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
     tot += 5 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user x2, r_news
     tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
+    tot += (align_up((size_t)B, 64) + align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)) * 4    // live-row counts, offsets, list
+           + align_up((size_t)B * U, 256);                                                                    // and flags
     return tot;
 }
 
@@ -2153,6 +2306,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     float* r_news = (float*)(ws + 3 * sb);
     float* const r_user2[2] = {r_user, (float*)(ws + 4 * sb)};
     void* xws_news = ws + 5 * sb;
+    int* live_ws = (int*)((char*)xws_news + digat_xattn_workspace_bytes(B, N, d));
 
     int rc;
     // user graph nodes = [history | topic nodes]  (:191)
@@ -2176,7 +2330,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, st, row_group, G, ue);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -2208,6 +2362,12 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         if (rc) return rc;
     }
     return DIGAT_OK;
+}
+
+int digat_set_live_row_skipping(int enabled) {
+    const int prev = g_live_rows_on;
+    g_live_rows_on = enabled ? 1 : 0;
+    return prev;
 }
 
 int digat_set_side_stream(int enabled) {
@@ -2259,6 +2419,9 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
                             base, stream, row_group, G);
 }
 
+static double g_prof_last_live_fraction = -1.0;
+double digat_profile_live_row_fraction(void) { return g_prof_last_live_fraction; }
+
 int digat_profile_start(int max_launches) {
     if (max_launches <= 0) return DIGAT_ERR_ARG;
     if (g_prof.ev) return DIGAT_ERR_ARG;          // already running
@@ -2268,6 +2431,9 @@ int digat_profile_start(int max_launches) {
     if (!g_prof.ev || !g_prof.kind || !g_prof.work) return DIGAT_ERR_ARG;
     for (int i = 0; i < 2 * max_launches; ++i)
         if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    if (hipMalloc((void**)&g_prof.rows_dev, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(g_prof.rows_dev, 0, sizeof(unsigned long long)) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    g_prof.flops_per_row = 0.0; g_prof.rows_kind = 0; g_prof.rows_nominal = 0.0;
     g_prof.cap = max_launches; g_prof.used = 0; g_prof.enabled = 1;
     return DIGAT_OK;
 }
@@ -2289,6 +2455,16 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         if (ms_per_kind) ms_per_kind[k] += ms;
         if (work_per_kind) work_per_kind[k] += g_prof.work[i];
         if (launches_per_kind) launches_per_kind[k] += 1;
+    }
+    g_prof_last_live_fraction = -1.0;
+    if (g_prof.rows_dev) {
+        unsigned long long rows = 0;
+        if (hipMemcpy(&rows, g_prof.rows_dev, sizeof(rows), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (work_per_kind) work_per_kind[g_prof.rows_kind] += (double)rows * g_prof.flops_per_row;
+            if (g_prof.rows_nominal > 0) g_prof_last_live_fraction = (double)rows / g_prof.rows_nominal;
+        }
+        hipFree(g_prof.rows_dev);
+        g_prof.rows_dev = nullptr;
     }
     for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
     free(g_prof.ev); free(g_prof.kind); free(g_prof.work);

@@ -170,6 +170,13 @@ int digat_encoder_fwd(const digat_params* params,
  * the previous setting.  Results do not depend on it. */
 int digat_set_side_stream(int enabled);
 
+/* User-graph nodes that cannot reach the encoder's outputs — no edge to another node, and pooled only into a
+ * masked category bucket: the history's padding slots and the topic nodes of unread categories
+ * (MIND_corpus.py:153-176) — are left out of the node projections of layers >= 1 by digat_encoder_fwd / _grouped
+ * (found on the device from user_graph, user_category_mask, user_category_indices; no host sync).  The outputs
+ * are unchanged.  0 projects every row (also: env DIGAT_NO_SKIP=1).  Returns the previous setting. */
+int digat_set_live_row_skipping(int enabled);
+
 /* The same inference for rows that SHARE users: in dev/test scoring the ~37 candidate rows of one
  * impression carry identical user tensors (util.py:57-67 expands them per row).  Here the user side is
  * passed once per group — user_news_embedding [G,H,d], user_graph [G,U,U], user_category_mask [G,C+1],
@@ -257,6 +264,10 @@ enum {
     DIGAT_KERNEL_KINDS = 7
 };
 int digat_profile_start(int max_launches);
+/* after digat_profile_stop: rows processed / rows nominal over the row-list projection launches of the profiled
+ * region (the encoder leaves the user-graph nodes that cannot reach its outputs out of the projections of
+ * layers >= 1), or -1 if there was none */
+double digat_profile_live_row_fraction(void);
 int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches_per_kind);
 
 #ifdef __cplusplus

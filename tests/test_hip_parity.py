@@ -366,3 +366,36 @@ def test_device_ranks_and_metrics_match_host(seed, impressions, max_c, quant):
     assert np.allclose(got_m, want_m, rtol=0, atol=1e-12), (got_m, want_m)
     only_r, none_m = evaluate.device_ranks_and_metrics(torch.from_numpy(scores).to(_dev()), imp)
     assert np.array_equal(only_r, want_r) and none_m is None
+
+
+def test_live_row_skipping_does_not_change_outputs():
+    """Projections restricted to the live user-graph nodes (default) vs every node: same scores, bit for bit.
+    The corpus has empty-history users (every category masked: padding slots are live there) and long histories."""
+    from digat_amd import synthetic, util, _lib
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=150, mean_candidates=30.0,
+                               max_candidates=80, seed=101)
+    corpus = synthetic.make_corpus(spec)
+    assert (corpus.user_category_mask.sum(axis=1) == 0).any(), "want at least one empty-history user"
+    L = 3
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=102, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    prev = _lib.lib().digat_set_live_row_skipping(0)
+    try:
+        every = util.score_rows(model, dc, 0, dc.rows, 1024)
+        every_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+        _lib.lib().digat_set_live_row_skipping(1)
+        live = util.score_rows(model, dc, 0, dc.rows, 1024)
+        live_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+    finally:
+        _lib.lib().digat_set_live_row_skipping(prev)
+    assert torch.equal(every, every_per_row)
+    assert torch.equal(live, every)
+    assert torch.equal(live_per_row, every)
