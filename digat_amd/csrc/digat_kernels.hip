@@ -1145,7 +1145,10 @@ __global__ void __launch_bounds__(256) xattn_score_small_kernel(const ScoreArgs 
 // loads h as one float4 and stores its 4 results as one float4.  h rows are requested AG_PF neighbour
 // steps ahead; alpha blocks (16 centres x 4 neighbours) that are entirely zero — masked pairs — skip
 // their MFMAs.
-struct AggArgs { const float* alpha; const float* Hh; const float* X; float* out; int B, n, d, groups, sa; };
+struct AggArgs {
+    const float* alpha; const float* Hh; const float* X; float* out; int B, n, d, groups, sa;
+    const uint8_t* live;     // optional [B,n]: rows of dead nodes (see user_live_flags_kernel) are neither read nor written
+};
 constexpr int AG_IT = 5;     // 16-row centre tiles per pass (80 centres)
 constexpr int AG_PF = 3;     // neighbour steps of h in flight
 
@@ -1155,11 +1158,16 @@ __global__ void __launch_bounds__(1024) xattn_agg_kernel(const AggArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int n = g.n, d = g.d, sa = g.sa;
+    unsigned char* lv = smem + (size_t)n * sa * 4;         // [n] live flags of this row's nodes (all 1 without a list)
+    for (int i = tid; i < n; i += blockDim.x) lv[i] = g.live ? g.live[(long)b * n + i] : 1;
+    __syncthreads();
     {
+        // a dead node's alpha row is never used (its output is not written) and its column is zero for every live
+        // centre (it has no edge to them): zero rows in the image let whole MFMA blocks drop out
         const float* Ab = g.alpha + (long)b * n * n;
         for (int e = tid; e < n * n; e += blockDim.x) {
             const int i = e / n, j = e - i * n;
-            As[i * sa + j] = Ab[e];
+            As[i * sa + j] = lv[i] ? Ab[e] : 0.f;
         }
     }
     __syncthreads();
@@ -1175,7 +1183,7 @@ __global__ void __launch_bounds__(1024) xattn_agg_kernel(const AggArgs g) {
 
     auto load_h = [&](int step) -> float4 {
         const int j = step * 4 + lq;
-        return (j < n && ch_ok) ? *reinterpret_cast<const float4*>(Hb + (long)j * d + ch) : f4_zero();
+        return (j < n && ch_ok && lv[j]) ? *reinterpret_cast<const float4*>(Hb + (long)j * d + ch) : f4_zero();
     };
 
     for (int it0 = 0; it0 < nit; it0 += AG_IT) {
@@ -1216,7 +1224,7 @@ __global__ void __launch_bounds__(1024) xattn_agg_kernel(const AggArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = (it0 + it) * 16 + 4 * lq + r;
-                    if (i < n) {
+                    if (i < n && lv[i]) {
                         const float4 x = *reinterpret_cast<const float4*>(Xb + (long)i * d + ch);
                         *reinterpret_cast<float4*>(Ob + (long)i * d + ch) =
                             make_float4(fmaxf(acc[it][0][r], 0.f) + x.x, fmaxf(acc[it][1][r], 0.f) + x.y,
@@ -1320,7 +1328,7 @@ static int launch_score(const XattnPlan& pl, hipStream_t st) {
 // Pr = K3 + K1 (r already added to the neighbour-side projection), see xattn_core
 static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h, const float* X,
                                  const float* a, const uint8_t* A, float* out, float* alpha,
-                                 int B, int n, int d, hipStream_t st) {
+                                 int B, int n, int d, hipStream_t st, const uint8_t* live = nullptr) {
     XattnPlan pl;
     const int rc = plan_xattn(B, n, d, &pl);
     if (rc) return rc;
@@ -1338,12 +1346,12 @@ static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h
         if (rc2) return rc2;
     }
     if (!(pl.g.skip & 2)) {
-        AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1};
+        AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1, live};
         if (ag.groups > 16) return DIGAT_ERR_SHAPE;        // d <= 1024
         // algorithmic bytes of the aggregation launch: h, X in + out (3 n d floats), alpha in;
         // flops 2 n^2 d per row run on the MFMA pipe
         ProfScope prof(DIGAT_KERNEL_AGG, (double)B * (3.0 * n * d * 4 + (double)n * n * 4.0), st);
-        hipLaunchKernelGGL(xattn_agg_kernel, dim3(B), dim3(64 * ag.groups), (size_t)n * ag.sa * 4, st, ag);
+        hipLaunchKernelGGL(xattn_agg_kernel, dim3(B), dim3(64 * ag.groups), (size_t)n * ag.sa * 4 + n, st, ag);
         DIGAT_CHECK_LAUNCH();
     }
     return DIGAT_OK;
@@ -1875,7 +1883,8 @@ int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, co
 static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
-                      const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr) {
+                      const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
+                      const uint8_t* live = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -1889,10 +1898,11 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.nsegs = 3;
     g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
     g.radd = r_given; g.radd_seg = 1; g.rows_per_b = n; // P' = K3 + K1: the reference's left-to-right order
-    if (rowidx && gemm_is_bf16x6(g)) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }   // live rows only (see user_live_rows_kernel)
+    const bool listed = rowidx && gemm_is_bf16x6(g);
+    if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
-    return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st);
+    return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st, listed ? live : nullptr);
 }
 
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
@@ -2226,7 +2236,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         } else {
             // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
-                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr);
+                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr);
         }
         if (rc) return rc;
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
