@@ -807,6 +807,7 @@ struct ScoreArgs {
     const float* P;    // P' = r + P  (K3 + K1)
     const float* Q; const float* a; const uint8_t* A; float* alpha;
     float* s_out;      // optional [B,n,n]: scores before leaky_relu / mask on the edges (training)
+    const uint8_t* live;   // optional [B,n]: 0 = dead node (see user_live_flags_kernel): its alpha row is not computed
     int B, n, d, d4;
     int NT, SN, CC4, nchunks, RB;
     int img_slots;     // float4 slots of one operand image of one chunk = RB * 4*NT * CC4
@@ -862,6 +863,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             const uint8_t* br = bytes + row * n + w * 32;
             const int lim = min(32, n - w * 32);
             for (int k = 0; k < lim; ++k) bits |= (br[k] != 0 ? 1u : 0u) << k;
+            if (g.live && !g.live[(long)b0 * n + row]) bits = 0;      // a dead node's row: no pair of it is ever needed
             Ab[e] = bits;
         }
     }
@@ -874,7 +876,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     int* node_of = keys + g.RB * n;                            // [RB*n]: node held by sorted slot sig
     for (int e = tid; e < rows_here * n; e += nthreads) {
         const int rb = e / n, i = e - rb * n;
-        int key = i;
+        int key = g.live ? n + i : i;        // rows without any bit (dead nodes, when a list is given) go last, together
         if (!(g.skip & 16)) {
             for (int w = 0; w < NW; ++w) {
                 const unsigned bits = Ab[e * NW + w];
@@ -918,7 +920,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             int sig = (pos % NT) * 4 + pos / NT;                               // sorted slot held by this image position
             if (sig >= n) sig = n - 1;                                         // padding positions: any real node
             if (rb >= rows_here) rb = rows_here - 1;
-            const int node = node_of[rb * n + sig];
+            int node = node_of[rb * n + sig];
+            if (g.live && !g.live[(long)(b0 + rb) * n + node]) node = node_of[rb * n];      // dead: re-read the first (live) node, never used
             src_off[k] = ((rb * n + node) * g.d + c4 * 4) | (op << 31);
         }
     }
@@ -1057,6 +1060,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     // ---- phase 2b: softmax over the neighbours j, one wave per (row, centre i); a row without any
     // edge is all -1e9 and comes out uniform, as in the reference
     for (int rho = wave; rho < ((g.skip & 8) ? 0 : rows_here * n); rho += nwaves) {
+        if (g.live && !g.live[(long)b0 * n + rho]) continue;           // dead centre: its alpha row keeps its (finite) old values
         const float* srow = Ss + (long)rho * SN;
         const float v0 = lane < n ? srow[lane] : -INFINITY;
         const float v1 = lane + 64 < n ? srow[lane + 64] : -INFINITY;
@@ -1333,7 +1337,7 @@ static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h
     const int rc = plan_xattn(B, n, d, &pl);
     if (rc) return rc;
     if (B == 0) return DIGAT_OK;
-    pl.g.P = Pr; pl.g.Q = Q; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha;
+    pl.g.P = Pr; pl.g.Q = Q; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha; pl.g.live = live;
     {
         static int skip = -1;
         if (skip < 0) { const char* e = getenv("DIGAT_XATTN_SKIP"); skip = e ? atoi(e) : 0; }
