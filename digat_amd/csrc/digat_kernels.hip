@@ -1774,6 +1774,26 @@ __global__ void __launch_bounds__(256) user_live_flags_kernel(const uint8_t* Au,
     if (lane == 0) cnt[b] = count;
 }
 
+// The pooled topic buckets [B, C+1] feed featureAffine and then the user attention, which masks every category the
+// user never read (weight exactly 0): only the unmasked buckets of a row are live — or all of them when no category
+// is unmasked (uniform attention).
+__global__ void __launch_bounds__(256) bucket_live_flags_kernel(const uint8_t* cat_mask, int B, int C1, uint8_t* flags, int* cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    bool any_cat = false;
+    for (int c = lane; c < C1; c += 64) any_cat |= cat_mask[(long)b * C1 + c] != 0;
+    any_cat = __any(any_cat);
+    int count = 0;
+    for (int c0 = 0; c0 < C1; c0 += 64) {
+        const int c = c0 + lane;
+        const bool live = c < C1 && (!any_cat || cat_mask[(long)b * C1 + c] != 0);
+        if (c < C1) flags[(long)b * C1 + c] = live ? 1 : 0;
+        count += __popcll(__ballot(live));
+    }
+    if (lane == 0) cnt[b] = count;
+}
+
 __global__ void __launch_bounds__(256) live_list_kernel(const uint8_t* flags, const int* off, int B, int U, int* rowidx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -2122,6 +2142,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
     float* T2 = (float*)((char*)cws + s2);        // after featureAffine
     float* glob = (float*)((char*)cws + 2 * s2);  // [B,d]; cws holds >= 2*s2 + 2*[B,d] (user-context layout)
+    const int* bucket_idx = nullptr;              // live topic buckets (set by find_live_rows during layer 0)
+    const int* nbuckets_dev = nullptr;
     int rc;
     // the user-side queries + (optionally) the next user-graph K3, all from c_n
     auto from_c_n = [&](int next_layer, hipStream_t sq) -> int {
@@ -2140,6 +2162,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
         g.wsplit = (const unsigned short*)p->featureAffine_wsplit;       // non-NULL: bf16x6
+        if (bucket_idx && gemm_is_bf16x6(g)) { g.rowidx = bucket_idx; g.nrows_dev = nbuckets_dev; }   // unmasked buckets only
         e = launch_gemm(g, st);
         if (e) return e;
         return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, st);
@@ -2161,12 +2184,16 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     const int* rowidx = nullptr;
     const int* nrows_dev = nullptr;
     uint8_t* live_flags = nullptr;
-    auto find_live_rows = [&](hipStream_t sq) -> int {     // needed from layer 1 on: runs beside layer 0
+    auto find_live_rows = [&](hipStream_t sq) -> int {     // needed after layer 0's Eq. 8: runs beside it
         int* cnt = live_ws;
         int* off = cnt + align_up((size_t)B, 64);
         int* idx = off + align_up((size_t)B + 1, 64);
-        live_flags = (uint8_t*)(idx + align_up((size_t)B * U, 64));
-        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + C1 + H * 8.0) + (double)B * U * 6, sq);
+        int* cnt2 = idx + align_up((size_t)B * U, 64);
+        int* off2 = cnt2 + align_up((size_t)B, 64);
+        int* idx2 = off2 + align_up((size_t)B + 1, 64);
+        live_flags = (uint8_t*)(idx2 + align_up((size_t)B * C1, 64));
+        uint8_t* flags2 = live_flags + align_up((size_t)B * U, 256);
+        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
                            live_flags, cnt);
         DIGAT_CHECK_LAUNCH();
@@ -2174,10 +2201,17 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)live_flags, (const int*)off, B, U, idx);
         DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bucket_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, cat_mask, B, C1, flags2, cnt2);
+        DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt2, off2, B);
+        DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags2, (const int*)off2, B, C1, idx2);
+        DIGAT_CHECK_LAUNCH();
         rowidx = idx; nrows_dev = off + B;
+        bucket_idx = idx2; nbuckets_dev = off2 + B;
         return DIGAT_OK;
     };
-    const bool want_live = L > 1 && g_live_rows_on && live_ws;
+    const bool want_live = L > 0 && g_live_rows_on && live_ws;
     SideStream* side = side_stream();
     rc = from_c_n(0, st);
     if (rc) return rc;
@@ -2278,8 +2312,9 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += max_sz(digat_news_ctx_workspace_bytes(B, N, d), digat_user_ctx_workspace_bytes(B, U, H, C + 1, d));
     tot += 5 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user x2, r_news
     tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
-    tot += (align_up((size_t)B, 64) + align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)) * 4    // live-row counts, offsets, list
-           + align_up((size_t)B * U, 256);                                                                    // and flags
+    // live-node and live-bucket counts, offsets, lists (int) and flags (bytes)
+    tot += (2 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
+            + align_up((size_t)B * (C + 1), 64)) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256);
     return tot;
 }
 
