@@ -146,6 +146,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop()
+    live_fraction = float(_lib.lib().digat_profile_live_row_fraction())
 
     # The timed region overlaps the news-graph kernels with the user graph's on a side stream, so the launch
     # durations above include the sharing.  A second, untimed pass on one stream gives each kernel's duration
@@ -313,6 +314,9 @@ def main():
         "roofline": roof(dom),
         "roofline_xattn": roof("xattn") if "xattn" in kinds else None,
         "kernel_ms_per_step": kernel_ms,
+        # rows projected / rows nominal over the row-list launches (user-graph layers >= 1 and featureAffine): the encoder
+        # leaves out nodes and topic buckets that cannot reach its outputs; the proj roofline prices EXECUTED flops
+        "live_row_fraction": live_fraction if live_fraction >= 0 else None,
         "cpu_baseline": cpu_baseline,
         "auc_match": auc_match,
     }

@@ -36,9 +36,9 @@ static struct {
     hipEvent_t* ev;
     int* kind;
     double* work;
-    unsigned long long* rows_dev;      // row-list GEMM launches add the rows they actually processed (device counter)
-    double flops_per_row; int rows_kind; double rows_nominal;
-} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.0, 0, 0.0};
+    unsigned long long* rows_dev;      // [kinds] row-list GEMM launches add the rows they actually processed (device counters)
+    double flops_per_row[16]; double rows_nominal[16];
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}};
 
 struct ProfScope {
     hipStream_t st; int slot;
@@ -737,8 +737,8 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int kind = DIGAT_KERNEL_LINEA
     // digat_profile_stop prices it; the launch itself is recorded with zero work
     const bool listed = g.rowidx != nullptr;
     if (listed && g_prof.enabled) {
-        g.exec_rows = g_prof.rows_dev;
-        g_prof.flops_per_row = 2.0 * (double)Ntot * g.K; g_prof.rows_kind = kind; g_prof.rows_nominal += g.M;
+        g.exec_rows = g_prof.rows_dev + kind;
+        g_prof.flops_per_row[kind] = 2.0 * (double)Ntot * g.K; g_prof.rows_nominal[kind] += g.M;
     }
     ProfScope prof(kind, listed ? 0.0 : 2.0 * g.M * (double)Ntot * g.K, st);
     if (g.wsplit && cfg == 0 && g.nseg % 80 == 0 && g.K % 8 == 0 && g.K >= 32 && g.ldy % 4 == 0 && g.lde0 % 4 == 0 && (g.epi == EPI_NONE || g.epi == EPI_RELU_RES) &&
@@ -2480,9 +2480,9 @@ int digat_profile_start(int max_launches) {
     if (!g_prof.ev || !g_prof.kind || !g_prof.work) return DIGAT_ERR_ARG;
     for (int i = 0; i < 2 * max_launches; ++i)
         if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return DIGAT_ERR_LAUNCH;
-    if (hipMalloc((void**)&g_prof.rows_dev, sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(g_prof.rows_dev, 0, sizeof(unsigned long long)) != hipSuccess) return DIGAT_ERR_LAUNCH;
-    g_prof.flops_per_row = 0.0; g_prof.rows_kind = 0; g_prof.rows_nominal = 0.0;
+    if (hipMalloc((void**)&g_prof.rows_dev, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(g_prof.rows_dev, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    for (int k = 0; k < 16; ++k) { g_prof.flops_per_row[k] = 0.0; g_prof.rows_nominal[k] = 0.0; }
     g_prof.cap = max_launches; g_prof.used = 0; g_prof.enabled = 1;
     return DIGAT_OK;
 }
@@ -2507,10 +2507,12 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
     }
     g_prof_last_live_fraction = -1.0;
     if (g_prof.rows_dev) {
-        unsigned long long rows = 0;
-        if (hipMemcpy(&rows, g_prof.rows_dev, sizeof(rows), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (work_per_kind) work_per_kind[g_prof.rows_kind] += (double)rows * g_prof.flops_per_row;
-            if (g_prof.rows_nominal > 0) g_prof_last_live_fraction = (double)rows / g_prof.rows_nominal;
+        unsigned long long rows[16];
+        if (hipMemcpy(rows, g_prof.rows_dev, sizeof(rows), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k)
+                if (work_per_kind) work_per_kind[k] += (double)rows[k] * g_prof.flops_per_row[k];
+            if (g_prof.rows_nominal[DIGAT_KERNEL_PROJ] > 0)
+                g_prof_last_live_fraction = (double)rows[DIGAT_KERNEL_PROJ] / g_prof.rows_nominal[DIGAT_KERNEL_PROJ];
         }
         hipFree(g_prof.rows_dev);
         g_prof.rows_dev = nullptr;
