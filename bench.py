@@ -314,6 +314,8 @@ def main():
         "roofline": roof(dom),
         "roofline_xattn": roof("xattn") if "xattn" in kinds else None,
         "kernel_ms_per_step": kernel_ms,
+        "kernel_ms_per_step_single_stream": {k: round(v["ms"] / max(1, min(args.steps, 10)), 4)
+                                             for k, v in prof_iso.items() if v["launches"] > 0},
         # rows projected / rows nominal over the row-list launches (user-graph layers >= 1 and featureAffine): the encoder
         # leaves out nodes and topic buckets that cannot reach its outputs; the proj roofline prices EXECUTED flops
         "live_row_fraction": live_fraction if live_fraction >= 0 else None,

@@ -14,8 +14,8 @@ SRC = os.path.join(HERE, "csrc", "digat_kernels.hip")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "digat_hip.h")
 OUT = os.path.join(HERE, "lib", "libdigat_hip.so")
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 FMAs into v_pk_fma_f32, which on
-# gfx950 issues far slower than two v_fma_f32 (MI355X_MICROARCH.md, cycle constants) — measured 1.6x
-# on the Eq. 8 kernel.
+# gfx950 issues slower than two v_fma_f32 (MI355X_MICROARCH.md, cycle constants) — measured 487 -> 452 us
+# on the Eq. 8 score kernel of that time.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
 
 
