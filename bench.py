@@ -164,9 +164,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rows_done], dtype=torch.float64, device=dev)
+        r = torch.tensor([rows_done, corpus.rows, spec.impressions], dtype=torch.float64, device=dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rows_total = float(r.item())
+        rows_total = float(r[0].item())
+        mean_cand = float(r[1].item()) / float(r[2].item())      # candidates per impression over every rank's shard
     else:
         rows_total = float(rows_done)
 
