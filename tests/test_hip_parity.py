@@ -399,3 +399,27 @@ def test_live_row_skipping_does_not_change_outputs():
     assert torch.equal(every, every_per_row)
     assert torch.equal(live, every)
     assert torch.equal(live_per_row, every)
+
+
+def test_encoder_call_is_graph_capturable():
+    """include/digat_hip.h promises: no allocation, no host synchronisation, side stream forked and joined through
+    events — so one encoder call can be captured into a hipGraph and replayed.  Replay must reproduce the eager bits."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 256, 10, 50, 17, 400, 3
+    state = synthetic.make_state_dict(d, C, L, seed=21, bias_std=0.05)
+    batch = to_dev(synthetic.make_encoder_batch(B, N, H, C, d, seed=22))
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    enc = make_encoder(state, N, H, C, d, L)
+    with torch.no_grad():
+        c_n0 = enc.compute_news_graph_context(batch["news_graph_embeddings"], batch["news_graph_mask"])
+        eager = enc.inference(*(batch[k] for k in keys), c_n0)      # also warms the workspace / folded weights
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = enc.inference(*(batch[k] for k in keys), c_n0)
+        for t in captured:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(captured[0], eager[0]) and torch.equal(captured[1], eager[1])
