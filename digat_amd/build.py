@@ -22,8 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-s
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(HEADER))
-    return os.path.getmtime(OUT) < newest
+    csrc = os.path.dirname(SRC)
+    sources = [HEADER] + [os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith((".hip", ".inc", ".h"))]
+    return os.path.getmtime(OUT) < max(os.path.getmtime(p) for p in sources)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
