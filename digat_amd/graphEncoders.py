@@ -318,7 +318,7 @@ class DIGAT(GraphEncoder):
         B, N, d = Xn.shape
         G = ue.shape[0]
         H, C = self.max_history_num, self.category_num - 1
-        if 4 * G > B or self.training:                 # too few rows per group to pay off: expand and take the plain path
+        if B == 0 or 4 * G > B or self.training:       # empty batch, or too few rows per group to pay off: expand, plain path
             rg = row_group.long()
             return self.inference(Xn, news_graph, news_graph_mask, ue.index_select(0, rg), user_graph.index_select(0, rg),
                                   user_category_mask.index_select(0, rg), user_category_indices.index_select(0, rg),
