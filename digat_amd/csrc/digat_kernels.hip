@@ -1722,7 +1722,9 @@ __global__ void __launch_bounds__(256) build_user_nodes_kernel(const float4* ue,
 // evolving from stale-but-finite values that nothing reads).  Live means:
 //   any off-diagonal entry in the node's adjacency row or column, or
 //   a history slot whose category is unmasked, or any history slot of a row with NO unmasked category (the
-//   context attention is then uniform over all C+1 buckets: util E2, the empty-history user).
+//   context attention is then uniform over all C+1 buckets: util E2, the empty-history user), or
+//   any node at all when some adjacency row of the graph has no entry, not even the self loop (E5: that centre's
+//   scores are all -1e9, its softmax is uniform over EVERY node).
 // One wave per row b.  Lane i builds the bit mask of row i of the adjacency (diagonal cleared); a node has an
 // off-diagonal entry in its row iff its mask is non-zero, and in its column iff its bit is set in the OR of all
 // the masks.  flags [B,U] bytes and cnt [B] are written; after the scan, live_list_kernel writes the row indices
@@ -1739,6 +1741,7 @@ __global__ void __launch_bounds__(256) user_live_flags_kernel(const uint8_t* Au,
     // U <= DIGAT_MAX_NODES = 128: two nodes per lane, masks of 4 x 32 bits
     unsigned rm[2][4];
     unsigned cm[4] = {0u, 0u, 0u, 0u};
+    bool empty_row = false;          // a row without ANY entry (not even the self loop) is all -1e9: uniform over every node
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
@@ -1746,12 +1749,17 @@ __global__ void __launch_bounds__(256) user_live_flags_kernel(const uint8_t* Au,
         for (int w = 0; w < 4; ++w) rm[h][w] = 0u;
         if (i < U) {
             const uint8_t* row = A + (long)i * U;
-            for (int j = 0; j < U; ++j)
+            bool any = false;
+            for (int j = 0; j < U; ++j) {
+                any |= row[j] != 0;
                 if (row[j] && j != i) rm[h][j >> 5] |= 1u << (j & 31);
+            }
+            empty_row |= !any;
         }
 #pragma unroll
         for (int w = 0; w < 4; ++w) cm[w] |= rm[h][w];
     }
+    const bool all_live = __any(empty_row);     // such a centre reads every node of the row: nothing may be left out
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
@@ -1762,7 +1770,7 @@ __global__ void __launch_bounds__(256) user_live_flags_kernel(const uint8_t* Au,
         const int i = lane + 64 * h;
         bool live = false;
         if (i < U) {
-            live = (rm[h][0] | rm[h][1] | rm[h][2] | rm[h][3]) != 0u || ((cm[i >> 5] >> (i & 31)) & 1u);
+            live = all_live || (rm[h][0] | rm[h][1] | rm[h][2] | rm[h][3]) != 0u || ((cm[i >> 5] >> (i & 31)) & 1u);
             if (i < H) {
                 const long c = cat_idx[(long)b * H + i];
                 live |= !any_cat || (c >= 0 && c < C1 && cat_mask[(long)b * C1 + c] != 0);

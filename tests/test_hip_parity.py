@@ -423,3 +423,50 @@ def test_encoder_call_is_graph_capturable():
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(captured[0], eager[0]) and torch.equal(captured[1], eager[1])
+
+
+def test_edge_cases_at_production_shapes_with_row_lists_active():
+    """E1-E5 at d=400, U=67 and a batch large enough that the row lists (live nodes, live buckets) are
+    in use: empty histories, isolated candidates, single-category histories, adjacency rows without any edge (not
+    even the self loop, graph no longer symmetric).  HIP (per-row and grouped) vs the oracle."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 128, 10, 50, 17, 400, 3
+    state = synthetic.make_state_dict(d, C, L, seed=41, bias_std=0.05)
+    G = B // 4                                                     # 4 candidate rows per user
+    users = synthetic.make_encoder_batch(G, N, H, C, d, seed=42, empty_history_rows=(1, 7, 20))
+    hist_len = np.full(G, H, dtype=np.int64)
+    g1, cm1, ci1 = synthetic.build_user_graphs(np.zeros((G, H), dtype=np.int64), hist_len, C)
+    for r in (3, 9):                                               # every history item in one category
+        users["user_graph"][r], users["user_category_mask"][r], users["user_category_indices"][r] = g1[r], cm1[r], ci1[r]
+    users["user_graph"][5, 0, :] = False                           # rows without any edge
+    users["user_graph"][5, H + 1, :] = False
+    users["user_graph"][11, H - 1, :] = False
+    users["user_graph"][11, :, H - 1] = False                      # ... and a node nobody attends to either
+    cands = synthetic.make_encoder_batch(B, N, H, C, d, seed=43, isolated_news_rows=(2, 4, 64, 127))
+    cands["news_graph"][6, 1, :] = False
+    row_group = np.repeat(np.arange(G), 4).astype(np.int32)
+    ukeys = ("user_news_embedding", "user_graph", "user_category_mask", "user_category_indices")
+    per_row = {k: (users[k][row_group] if k in ukeys else cands[k]) for k in
+               ("news_graph_embeddings", "news_graph", "news_graph_mask") + ukeys}
+    p = O.as_params(state)
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in per_row.items()}
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, tb["news_graph_embeddings"], tb["news_graph_mask"])
+        want_n, want_u = O.encoder_inference(p, L, tb["news_graph_embeddings"], tb["news_graph"], tb["news_graph_mask"],
+                                             tb["user_news_embedding"], tb["user_graph"], tb["user_category_mask"],
+                                             tb["user_category_indices"], c_n0)
+    enc = make_encoder(state, N, H, C, d, L)
+    db = to_dev(per_row)
+    du = to_dev({k: users[k] for k in ukeys})
+    with torch.no_grad():
+        c0 = enc.compute_news_graph_context(db["news_graph_embeddings"], db["news_graph_mask"])
+        got_n, got_u = enc.inference(db["news_graph_embeddings"], db["news_graph"], db["news_graph_mask"],
+                                     db["user_news_embedding"], db["user_graph"], db["user_category_mask"],
+                                     db["user_category_indices"], c0)
+        grp_n, grp_u = enc.inference_grouped(db["news_graph_embeddings"], db["news_graph"], db["news_graph_mask"],
+                                             du["user_news_embedding"], du["user_graph"], du["user_category_mask"],
+                                             du["user_category_indices"], torch.from_numpy(row_group).to(_dev()), c0)
+    close(c0, c_n0, "edges@400: c_n0")
+    close(got_n, want_n, "edges@400: news ctx", rtol=2e-5, atol=2e-5)
+    close(got_u, want_u, "edges@400: user ctx", rtol=2e-5, atol=2e-5)
+    assert torch.equal(grp_n, got_n) and torch.equal(grp_u, got_u)
