@@ -316,14 +316,15 @@ def test_grouped_inference_is_bit_identical_to_per_row():
     assert torch.equal(a, b)
 
 
-def test_side_stream_schedule_is_bit_identical_to_single_stream():
+@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18)],
+                         ids=["default", "stress-N65-L7", "large-N26"])
+def test_side_stream_schedule_is_bit_identical_to_single_stream(neighbors, hops, L, cats):
     """The news-graph chain on the side stream (default) vs everything on the caller's stream."""
     from digat_amd import synthetic, util, _lib
     from digat_amd.model import Model, PrecomputedNewsEncoder
-    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=120, mean_candidates=30.0,
-                               max_candidates=80, seed=91)
+    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=neighbors, sag_hops=hops, category_num=cats, impressions=120,
+                               mean_candidates=30.0, max_candidates=80, seed=91)
     corpus = synthetic.make_corpus(spec)
-    L = 3
     state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=92, bias_std=0.05)
     cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
                                 max_history_num=spec.max_history_num, category_num=spec.category_num,
@@ -368,16 +369,17 @@ def test_device_ranks_and_metrics_match_host(seed, impressions, max_c, quant):
     assert np.array_equal(only_r, want_r) and none_m is None
 
 
-def test_live_row_skipping_does_not_change_outputs():
+@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18)],
+                         ids=["default", "stress-N65-L7", "large-N26"])
+def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     """Projections restricted to the live user-graph nodes (default) vs every node: same scores, bit for bit.
     The corpus has empty-history users (every category masked: padding slots are live there) and long histories."""
     from digat_amd import synthetic, util, _lib
     from digat_amd.model import Model, PrecomputedNewsEncoder
-    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=150, mean_candidates=30.0,
-                               max_candidates=80, seed=101)
+    spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=neighbors, sag_hops=hops, category_num=cats, impressions=150,
+                               mean_candidates=30.0, max_candidates=80, seed=101)
     corpus = synthetic.make_corpus(spec)
     assert (corpus.user_category_mask.sum(axis=1) == 0).any(), "want at least one empty-history user"
-    L = 3
     state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=102, bias_std=0.05)
     cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
                                 max_history_num=spec.max_history_num, category_num=spec.category_num,
