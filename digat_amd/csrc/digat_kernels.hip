@@ -808,6 +808,7 @@ struct ScoreArgs {
     const float* Q; const float* a; const uint8_t* A; float* alpha;
     float* s_out;      // optional [B,n,n]: scores before leaky_relu / mask on the edges (training)
     const uint8_t* live;   // optional [B,n]: 0 = dead node (see user_live_flags_kernel): its alpha row is not computed
+    const int* qgroup;     // optional [B]: row b's Q lives at Q[qgroup[b]] (rows of one impression share the centre-side projection)
     int B, n, d, d4;
     int NT, SN, CC4, nchunks, RB;
     int img_slots;     // float4 slots of one operand image of one chunk = RB * 4*NT * CC4
@@ -900,7 +901,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 
     // ---- this wave's DMA pieces: instruction q = wave + nwaves*k covers image slots [64q, 64q+64)
     const float* Pblk = g.P + (long)b0 * n * g.d;
-    const float* Qblk = g.Q + (long)b0 * n * g.d;
+    const float* Qblk = g.qgroup ? g.Q : g.Q + (long)b0 * n * g.d;      // grouped: offsets below are absolute rows of Q
     int src_off[XA_KMAX];        // float offset of this lane's source at chunk 0; bit 31: Q operand
     int kw = 0;                  // wave-uniform: instructions this wave issues per chunk
 #pragma unroll
@@ -922,7 +923,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             if (rb >= rows_here) rb = rows_here - 1;
             int node = node_of[rb * n + sig];
             if (g.live && !g.live[(long)(b0 + rb) * n + node]) node = node_of[rb * n];      // dead: re-read the first (live) node, never used
-            src_off[k] = ((rb * n + node) * g.d + c4 * 4) | (op << 31);
+            const int brow = (op && g.qgroup) ? g.qgroup[b0 + rb] : rb;
+            src_off[k] = ((brow * n + node) * g.d + c4 * 4) | (op << 31);
         }
     }
     auto issue = [&](int ch, int buf) {
@@ -1088,7 +1090,7 @@ __global__ void __launch_bounds__(256) xattn_score_small_kernel(const ScoreArgs 
     if (rho >= (long)g.B * n) return;
     const long b = rho / n;
     const float4* a4 = reinterpret_cast<const float4*>(g.a);
-    const float4* Qi = reinterpret_cast<const float4*>(g.Q) + rho * d4;
+    const float4* Qi = reinterpret_cast<const float4*>(g.Q) + (g.qgroup ? (long)g.qgroup[b] * n + (rho - b * n) : rho) * d4;
     const float4* Pb = reinterpret_cast<const float4*>(g.P) + b * n * d4;
     float4 q[U], av[U];
 #pragma unroll
@@ -1152,6 +1154,7 @@ __global__ void __launch_bounds__(256) xattn_score_small_kernel(const ScoreArgs 
 struct AggArgs {
     const float* alpha; const float* Hh; const float* X; float* out; int B, n, d, groups, sa;
     const uint8_t* live;     // optional [B,n]: rows of dead nodes (see user_live_flags_kernel) are neither read nor written
+    const int* hgroup;       // optional [B]: row b's h lives at Hh[hgroup[b]]
 };
 constexpr int AG_IT = 5;     // 16-row centre tiles per pass (80 centres)
 constexpr int AG_PF = 3;     // neighbour steps of h in flight
@@ -1179,7 +1182,7 @@ __global__ void __launch_bounds__(1024) xattn_agg_kernel(const AggArgs g) {
     const int lr = lane & 15, lq = lane >> 4;
     const int ch = wave * 64 + 4 * lr;
     const bool ch_ok = ch < d;
-    const float* Hb = g.Hh + (long)b * n * d;
+    const float* Hb = g.Hh + (long)(g.hgroup ? g.hgroup[b] : b) * n * d;
     const float* Xb = g.X + (long)b * n * d;
     float* Ob = g.out + (long)b * n * d;
     const int nit = (n + 15) >> 4;
@@ -1332,12 +1335,12 @@ static int launch_score(const XattnPlan& pl, hipStream_t st) {
 // Pr = K3 + K1 (r already added to the neighbour-side projection), see xattn_core
 static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h, const float* X,
                                  const float* a, const uint8_t* A, float* out, float* alpha,
-                                 int B, int n, int d, hipStream_t st, const uint8_t* live = nullptr) {
+                                 int B, int n, int d, hipStream_t st, const uint8_t* live = nullptr, const int* group = nullptr) {
     XattnPlan pl;
     const int rc = plan_xattn(B, n, d, &pl);
     if (rc) return rc;
     if (B == 0) return DIGAT_OK;
-    pl.g.P = Pr; pl.g.Q = Q; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha; pl.g.live = live;
+    pl.g.P = Pr; pl.g.Q = Q; pl.g.a = a; pl.g.A = A; pl.g.alpha = alpha; pl.g.live = live; pl.g.qgroup = group;
     {
         static int skip = -1;
         if (skip < 0) { const char* e = getenv("DIGAT_XATTN_SKIP"); skip = e ? atoi(e) : 0; }
@@ -1350,7 +1353,7 @@ static int launch_xattn_pairwise(const float* Pr, const float* Q, const float* h
         if (rc2) return rc2;
     }
     if (!(pl.g.skip & 2)) {
-        AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1, live};
+        AggArgs ag{alpha, h, X, out, B, n, d, (d + 63) / 64, n | 1, live, group};
         if (ag.groups > 16) return DIGAT_ERR_SHAPE;        // d <= 1024
         // algorithmic bytes of the aggregation launch: h, X in + out (3 n d floats), alpha in;
         // flops 2 n^2 d per row run on the MFMA pipe
@@ -1847,18 +1850,15 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const uint8_t* in, uin
 }
 
 // layer-0 user graph of grouped rows: h[b] = h0[g], P'[b] = r[b] + P0[g] (K3 + K1), Q[b] = Q0[g]
-__global__ void __launch_bounds__(256) expand_proj_kernel(const float4* h0, const float4* P0, const float4* Q0, const float4* r,
-                                                          const int* group, float4* h, float4* Pr, float4* Q, long B, int n, int d4) {
+__global__ void __launch_bounds__(256) expand_proj_kernel(const float4* P0, const float4* r, const int* group, float4* Pr,
+                                                          long B, int n, int d4) {
     const long per_row = (long)n * d4;
     const long total = B * per_row;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long b = i / per_row;
         const long rem = i - b * per_row;
-        const long src = (long)group[b] * per_row + rem;
         const int c4 = (int)(rem % d4);
-        h[i] = h0[src];
-        Q[i] = Q0[src];
-        Pr[i] = f4_add(r[b * d4 + c4], P0[src]);
+        Pr[i] = f4_add(r[b * d4 + c4], P0[(long)group[b] * per_row + rem]);
     }
 }
 
@@ -2238,13 +2238,17 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         // ---- user graph, Eq. 8 (caller's stream)
         if (i == 0 && row_group) {
-            // layer 0 of grouped rows: every row of a group has the same user nodes, so project the G groups
-            // once ([G*U] rows instead of [B*U]) and expand h | P' = r + P | Q per row
+            // layer 0 of grouped rows: every row of a group has the same user nodes, so project the G groups once
+            // ([G*U] rows instead of [B*U]).  h and Q of a group go straight to the h / Q slots of the Eq. 8 workspace
+            // and are read through the group index by the aggregation / score kernels (the 37 rows of an impression
+            // share them: they stay in L2); only P' = K3_b + P depends on the row and is expanded.
             const size_t ndg = (size_t)G * U * d;
-            float* Xg = Xu[1];                                  // free until this layer's output is written
-            float* h0 = Xg + ndg;                               // G << B: all four fit in the [B,U,d] buffer
-            float* P0 = h0 + ndg;
-            float* Q0 = P0 + ndg;
+            const size_t nd = (size_t)B * U * d;
+            float* Xg = Xu[1];                                  // group nodes and P of the groups: free until this
+            float* P0 = Xg + ndg;                               // layer's output is written (2 ndg <= nd)
+            float* h0 = (float*)xws;
+            float* P = h0 + nd;
+            float* Q0 = P + nd;
             {
                 const long total4 = (long)ndg / 4;
                 int blocks = (int)((total4 + 255) / 256);
@@ -2261,24 +2265,17 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
             rc = launch_gemm(gg, st, DIGAT_KERNEL_PROJ);
             if (rc) return rc;
-            const size_t nd = (size_t)B * U * d;
-            float* h = (float*)xws;
-            float* P = h + nd;
-            float* Q = P + nd;
             float* alpha = (float*)((char*)xws + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
             {
                 const long total4 = (long)nd / 4;
                 int blocks = (int)((total4 + 255) / 256);
                 if (blocks > 4096) blocks = 4096;
-                ProfScope prof(DIGAT_KERNEL_GLUE, (double)nd * 4 * 3, st);
-                hipLaunchKernelGGL(expand_proj_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)h0, (const float4*)P0,
-                                   (const float4*)Q0, (const float4*)r_user, row_group, (float4*)h, (float4*)P, (float4*)Q,
-                                   (long)B, U, d / 4);
+                ProfScope prof(DIGAT_KERNEL_GLUE, (double)nd * 4, st);
+                hipLaunchKernelGGL(expand_proj_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)P0, (const float4*)r_user,
+                                   row_group, (float4*)P, (long)B, U, d / 4);
                 DIGAT_CHECK_LAUNCH();
             }
-            // Xu[1] is about to be overwritten by the layer output while h0/P0/Q0 live there: they are consumed
-            // (expanded) before the pairwise kernels run, and the output is written only by the aggregation
-            rc = launch_xattn_pairwise(P, Q, h, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st);
+            rc = launch_xattn_pairwise(P, Q0, h0, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st, nullptr, row_group);
         } else {
             // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
