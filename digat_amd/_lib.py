@@ -69,6 +69,7 @@ _SIGNATURES = {
     "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
     "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),
     "digat_linear_bwd_input": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f]),
+    "digat_linear_bwd_input_x3": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f]),
     "digat_linear_bwd_weight_workspace": (C.c_size_t, [C.c_int] * 3),
     "digat_linear_bwd_weight": (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f,
                                           C.c_size_t, _f]),
@@ -85,6 +86,7 @@ _SIGNATURES = {
     "digat_topic_pool_fwd_train": (C.c_int, [_f] * 5 + [C.c_int] * 5 + [_f]),
     "digat_topic_pool_bwd": (C.c_int, [_f] * 7 + [C.c_int] * 5 + [_f]),
     "digat_xattn_project": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f]),
+    "digat_xattn_project_x3": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f, _f]),
     "digat_xattn_pairwise_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32, C.c_int, C.c_int, C.c_int, _f]),
     "digat_xattn_pairwise_bwd_workspace": (C.c_size_t, [C.c_int] * 3),
     "digat_xattn_pairwise_bwd": (C.c_int, [_f] * 11 + [C.c_float] + [_f] * 4 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),

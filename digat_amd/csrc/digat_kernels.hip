@@ -199,11 +199,12 @@ size_t digat_split_weights_bytes(int rows, int K) {
     return (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;       // one 15 KB image per (80-row strip, K tile)
 }
 
-static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st) {
+static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st,
+                        int transposed = 0) {
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit);
+    hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit, transposed);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }

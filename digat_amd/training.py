@@ -43,6 +43,33 @@ def _rows(x: torch.Tensor):
     return x, x.numel() // K, K, K
 
 
+def _x3_ok(M, n_out, k_in):
+    """Shapes the bf16x6 matrix-core kernel serves (fp32-grade: exact 3-way bf16 split, 6 products, fp32 accumulate)."""
+    return M >= 2048 and n_out % 80 == 0 and k_in % 8 == 0 and k_in >= 32
+
+
+def _wsplit(n_out, k_in, dev):
+    nb = L().digat_split_weights_bytes(n_out, k_in)
+    return _lib.workspace(nb, dev, "wsplit")     # rewritten by every call (weights change each step); stream-ordered reuse
+
+
+def _linear_fwd(x_ptr, ld, W, b_ptr, y_ptr, M, N, K, dev, what):
+    """y[M,N] = x[M,K] W[N,K]^T (+ b)"""
+    if _x3_ok(M, N, K) and ld % 4 == 0:
+        _lib.check(L().digat_linear_f32x3(x_ptr, ld, W.data_ptr(), b_ptr, y_ptr, N, M, N, K, _wsplit(N, K, dev).data_ptr(), S()), what)
+    else:
+        _lib.check(L().digat_linear_f32(x_ptr, ld, W.data_ptr(), b_ptr, y_ptr, N, M, N, K, S()), what)
+
+
+def _linear_bwd_input(dy_ptr, W, dx_ptr, M, N, K, accumulate, dev, what):
+    """dx[M,K] (+)= dy[M,N] W[N,K]"""
+    if _x3_ok(M, K, N):
+        _lib.check(L().digat_linear_bwd_input_x3(dy_ptr, N, W.data_ptr(), dx_ptr, K, M, N, K, accumulate,
+                                                 _wsplit(K, N, dev).data_ptr(), S()), what)
+    else:
+        _lib.check(L().digat_linear_bwd_input(dy_ptr, N, W.data_ptr(), dx_ptr, K, M, N, K, accumulate, S()), what)
+
+
 class Linear(Function):
     """y = x W^T + b  (W [N,K] as in nn.Linear)."""
 
@@ -52,8 +79,7 @@ class Linear(Function):
         N = W.shape[0]
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         if M:
-            _lib.check(L().digat_linear_f32(x.data_ptr(), ld, W.data_ptr(), _lib.ptr(b), y.data_ptr(), N, M, N, K, S()),
-                       "digat_linear_f32")
+            _linear_fwd(x.data_ptr(), ld, W, _lib.ptr(b), y.data_ptr(), M, N, K, x.device, "digat_linear_f32")
         ctx.save_for_backward(x, W)
         ctx.dims = (M, N, K, ld, b is not None)
         return y
@@ -67,8 +93,7 @@ class Linear(Function):
         dW = torch.empty_like(W)
         db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
         if M:
-            _lib.check(L().digat_linear_bwd_input(dy.data_ptr(), N, W.data_ptr(), dx.data_ptr(), K, M, N, K, 0, S()),
-                       "digat_linear_bwd_input")
+            _linear_bwd_input(dy.data_ptr(), W, dx.data_ptr(), M, N, K, 0, x.device, "digat_linear_bwd_input")
             nb = L().digat_linear_bwd_weight_workspace(M, N, K)
             ws = _lib.workspace(nb, x.device, "dW")
             _lib.check(L().digat_linear_bwd_weight(dy.data_ptr(), N, x.data_ptr(), ld, dW.data_ptr(), _lib.ptr(db), M, N, K, 0,
@@ -89,7 +114,7 @@ class MatmulW(Function):
         M, N = x.shape
         K = W.shape[1]
         y = torch.empty((M, K), dtype=torch.float32, device=x.device)
-        _lib.check(L().digat_linear_bwd_input(x.data_ptr(), N, W.data_ptr(), y.data_ptr(), K, M, N, K, 0, S()), "matmul_w")
+        _linear_bwd_input(x.data_ptr(), W, y.data_ptr(), M, N, K, 0, x.device, "matmul_w")
         ctx.save_for_backward(x, W)
         return y
 
@@ -102,7 +127,7 @@ class MatmulW(Function):
         dx = torch.empty_like(x)
         dW = torch.empty_like(W)
         # dx = dy @ W^T  -> linear(dy, W);  dW[n][k] = sum_m x[m][n] dy[m][k]
-        _lib.check(L().digat_linear_f32(dy.data_ptr(), K, W.data_ptr(), None, dx.data_ptr(), N, M, N, K, S()), "matmul_w dx")
+        _linear_fwd(dy.data_ptr(), K, W, None, dx.data_ptr(), M, N, K, x.device, "matmul_w dx")
         nb = L().digat_linear_bwd_weight_workspace(M, N, K)
         ws = _lib.workspace(nb, x.device, "dW")
         _lib.check(L().digat_linear_bwd_weight(x.data_ptr(), N, dy.data_ptr(), K, dW.data_ptr(), None, M, N, K, 0,
@@ -243,8 +268,14 @@ class XattnLayer(Function):
         B, n, d = Xd.shape
         dev = Xd.device
         h, Pr, Q = (torch.empty_like(Xd) for _ in range(3))
-        _lib.check(L().digat_xattn_project(Xd.data_ptr(), r.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(), F2.data_ptr(),
-                                           h.data_ptr(), Pr.data_ptr(), Q.data_ptr(), B, n, d, S()), "digat_xattn_project")
+        if _x3_ok(B * n, d, d):
+            _lib.check(L().digat_xattn_project_x3(Xd.data_ptr(), r.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
+                                                  F2.data_ptr(), h.data_ptr(), Pr.data_ptr(), Q.data_ptr(), B, n, d,
+                                                  _wsplit(3 * d, d, dev).data_ptr(), S()), "digat_xattn_project_x3")
+        else:
+            _lib.check(L().digat_xattn_project(Xd.data_ptr(), r.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
+                                               F2.data_ptr(), h.data_ptr(), Pr.data_ptr(), Q.data_ptr(), B, n, d, S()),
+                       "digat_xattn_project")
         out = torch.empty_like(Xd)
         alpha = torch.empty((B, n, n), dtype=torch.float32, device=dev)
         s_pre = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
@@ -278,8 +309,7 @@ class XattnLayer(Function):
         # projections: dXd = dOut (residual) + dh W + dP' F1 + dQ F2
         dXd = dOut.clone()
         for g_, w_ in ((dh, W), (dPr, F1), (dQ, F2)):
-            _lib.check(L().digat_linear_bwd_input(g_.data_ptr(), d, w_.data_ptr(), dXd.data_ptr(), d, M, d, d, 1, S()),
-                       "digat_linear_bwd_input")
+            _linear_bwd_input(g_.data_ptr(), w_, dXd.data_ptr(), M, d, d, 1, dev, "digat_linear_bwd_input")
         dW, dF1, dF2 = torch.empty_like(W), torch.empty_like(F1), torch.empty_like(F2)
         dbW = torch.empty(d, dtype=torch.float32, device=dev)
         nbw = L().digat_linear_bwd_weight_workspace(M, d, d)

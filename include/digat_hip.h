@@ -203,7 +203,11 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
  * are ordered (no atomics), so gradients are run-to-run reproducible.  `accumulate` != 0 adds into the
  * destination. */
 int digat_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
-                           int M, int N, int K, int accumulate, void* stream);           /* dx[M,K] = dy[M,N] @ w[N,K] */
+                           int M, int N, int K, int accumulate, void* stream);
+/* The same on the bf16 matrix cores (bf16x6: fp32-grade).  W^T is split into `wsplit` (digat_split_weights_bytes(K, N)
+ * bytes) by every call — the weights change every optimiser step.  M >= 2048, K % 80 == 0, N % 8 == 0, N >= 32. */
+int digat_linear_bwd_input_x3(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
+                              int M, int N, int K, int accumulate, void* wsplit, void* stream);           /* dx[M,K] = dy[M,N] @ w[N,K] */
 size_t digat_linear_bwd_weight_workspace(int M, int No, int Ni);
 int digat_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db,
                             int M, int No, int Ni, int accumulate, void* workspace, size_t workspace_bytes,
@@ -227,6 +231,10 @@ int digat_topic_pool_bwd(const float* Xu, const float* kq, const int64_t* cat_id
                          float* dXu, float* dkq, int B, int U, int H, int C1, int d, void* stream);
 int digat_xattn_project(const float* X, const float* r, const float* W, const float* bW, const float* F1,
                         const float* F2, float* h, float* Pr, float* Q, int B, int n, int d, void* stream);
+/* ... with the bf16x6 kernel: [W|ffn1|ffn2] is split into `wsplit` (digat_split_weights_bytes(3 d, d) bytes) first.
+ * B*n >= 2048, d % 80 == 0. */
+int digat_xattn_project_x3(const float* X, const float* r, const float* W, const float* bW, const float* F1, const float* F2,
+                           float* h, float* Pr, float* Q, int B, int n, int d, void* wsplit, void* stream);
 int digat_xattn_pairwise_fwd_train(const float* Pr, const float* Q, const float* h, const float* X, const float* a,
                                    const uint8_t* A, float* out, float* alpha, float* s_pre, float* alpha_drop,
                                    uint8_t* amask, float p, uint32_t seed, int B, int n, int d, void* stream);
