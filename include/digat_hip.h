@@ -114,8 +114,9 @@ typedef struct digat_layer_params {
     const float *F2;          /* {g}_graph_attention_ffn2.i.weight        */
     const float *F3, *b3;     /* {g}_graph_attention_ffn3.i.{weight,bias} */
     const float *a;           /* {g}_graph_attention_a.i.weight  [1,d]    */
-    const void  *wsplit;      /* optional: [W|ffn1|ffn2] pre-split by digat_split_proj_weights
-                                 (3 bf16 planes, digat_split_weights_bytes(3d, d) bytes).  Non-NULL runs the
+    const void  *wsplit;      /* optional: [W|ffn1|ffn2] pre-split by digat_split_proj_weights (opaque: the
+                                 three bf16 pieces of every weight, arranged as LDS images per 80-row strip and
+                                 32-deep K tile; digat_split_weights_bytes(3d, d) bytes).  Non-NULL runs the
                                  node projections as six bf16 MFMA products per fp32 product ("bf16x6":
                                  fp32-equivalent accuracy, 6/16 of the fp32-MFMA cost); NULL = fp32 MFMA. */
 } digat_layer_params;
@@ -164,9 +165,9 @@ int digat_encoder_fwd(const digat_params* params,
                       int B, int N, int H,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* digat_encoder_fwd / _grouped run the news-graph kernels of a layer (small: N nodes, [B,d] linears) on an
- * internal side stream under the user graph's Eq. 8 and join before the user context is pooled (two events per
- * layer; capturable).  0 keeps every launch on the caller's stream (also: env DIGAT_SINGLE_STREAM=1).  Returns
+/* With the folded-query fields set, digat_encoder_fwd / _grouped run the news-graph kernels of a layer (small:
+ * N nodes, [B,d] linears) on an internal side stream under the user graph's Eq. 8 and join before the user
+ * context is pooled (two events per layer; capturable).  0 keeps every launch on the caller's stream (also: env DIGAT_SINGLE_STREAM=1).  Returns
  * the previous setting.  Results do not depend on it. */
 int digat_set_side_stream(int enabled);
 
