@@ -461,6 +461,27 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     };
     const bool want_live = L > 0 && g_live_rows_on && live_ws;
     SideStream* side = side_stream();
+    // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
+    // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
+    // layer i+1's under the pooling of user context i — instead of waiting for c_u.
+    const bool news_early = L > 0 && N <= 16 && d / 4 <= 256;       // same arithmetic with and without the side stream
+    auto news_project = [&](int layer, const float* Xn_cur, hipStream_t sq) -> int {
+        const digat_layer_params& ln = p->news[layer];
+        const size_t ndn = (size_t)B * N * d;
+        float* hn = (float*)xws_news;
+        GemmArgs gp = gemm_plain(Xn_cur, d, ln.W, ln.bW, hn, d, B * N, d, d, 0);
+        gp.w[1] = ln.F1; gp.bias[1] = nullptr; gp.y[1] = hn + ndn;
+        gp.w[2] = ln.F2; gp.bias[2] = nullptr; gp.y[2] = hn + 2 * ndn;
+        gp.nsegs = 3;
+        gp.wsplit = (const unsigned short*)ln.wsplit;
+        return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
+    };
+    if (news_early) {
+        if (side && (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess))
+            return DIGAT_ERR_LAUNCH;
+        rc = news_project(0, Xn_in, side ? side->s : st);
+        if (rc) return rc;
+    }
     rc = from_c_n(0, st);
     if (rc) return rc;
     rc = user_ctx_tail(Xu[0], nullptr);            // c_u (:192)
@@ -529,7 +550,14 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
         if (rc) return rc;
-        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
+        if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
+            const size_t ndn = (size_t)B * N * d;
+            float* hn = (float*)xws_news;
+            float* alpha_n = (float*)((char*)xws_news + align_up(3 * ndn * 4, 256) + align_up((size_t)B * d * 4, 256));
+            rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news);
+        } else {
+            rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
+        }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
         rc = news_ctx(xn_cur, sn);                 // c_n += ... (:196)
@@ -539,6 +567,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (side) {
             if (hipEventRecord(side->join, sn) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
                 return DIGAT_ERR_LAUNCH;
+        }
+        if (news_early && i + 1 < L) {             // the next layer's news projections need only Xn: under the user context
+            rc = news_project(i + 1, xn_cur, sn);
+            if (rc) return rc;
         }
         rc = user_ctx_tail(Xu[un], c_u);           // c_u += ... (:197)
         if (rc) return rc;
