@@ -362,7 +362,7 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // on a side stream under the user graph's projection / score / aggregation, which fill the chip; fork and join
 // are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
 // caller's stream.
-struct SideStream { hipStream_t s; hipEvent_t fork, join; int ok; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
 static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
 static SideStream* side_stream() {
@@ -374,7 +374,8 @@ static SideStream* side_stream() {
         SideStream& x = tab[dev];
         const bool ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
                         hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+                        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&x.early, hipEventDisableTiming) == hipSuccess;
         state[dev] = ok ? 1 : -1;
     }
     return state[dev] == 1 ? &tab[dev] : nullptr;
@@ -476,9 +477,45 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gp.wsplit = (const unsigned short*)ln.wsplit;
         return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
     };
-    if (news_early) {
-        if (side && (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess))
+    // layer 0 of grouped rows: every row of a group has the same user nodes, so the G groups are projected once
+    // ([G*U] rows instead of [B*U]).  h and Q of a group go straight to the h / Q slots of the Eq. 8 workspace and are
+    // read through the group index by the aggregation / score kernels (the 37 rows of an impression share them: they
+    // stay in L2); only P' = K3_b + P depends on the row and is expanded later.  Needs nothing but the inputs.
+    auto group_project = [&](hipStream_t sq) -> int {
+        const digat_layer_params& lu = p->user[0];
+        const size_t ndg = (size_t)G * U * d;
+        const size_t nd = (size_t)B * U * d;
+        float* Xg = Xu[1];                                  // group nodes and P of the groups: free until layer 0's
+        float* P0 = Xg + ndg;                               // output is written (2 ndg <= nd)
+        float* h0 = (float*)xws;
+        float* Q0 = h0 + 2 * nd;
+        const long total4 = (long)ndg / 4;
+        int blocks = (int)((total4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq, (const float4*)ue_groups,
+                           (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
+        DIGAT_CHECK_LAUNCH();
+        GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
+        gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
+        gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = Q0;
+        gg.nsegs = 3;
+        gg.wsplit = (const unsigned short*)lu.wsplit;
+        gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
+        return launch_gemm(gg, sq, DIGAT_KERNEL_PROJ);
+    };
+    // Work that depends on the inputs alone goes out on the side stream at once, under the initial user context:
+    // the group projections of layer 0 and (small news graphs) the news projections of layer 0.
+    const bool group_early = side && L > 0 && row_group;
+    if (side && (news_early || group_early)) {
+        if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
             return DIGAT_ERR_LAUNCH;
+    }
+    if (group_early) {
+        rc = group_project(side->s);
+        if (rc) return rc;
+        if (hipEventRecord(side->early, side->s) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    }
+    if (news_early) {
         rc = news_project(0, Xn_in, side ? side->s : st);
         if (rc) return rc;
     }
@@ -499,33 +536,18 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         // ---- user graph, Eq. 8 (caller's stream)
         if (i == 0 && row_group) {
-            // layer 0 of grouped rows: every row of a group has the same user nodes, so project the G groups once
-            // ([G*U] rows instead of [B*U]).  h and Q of a group go straight to the h / Q slots of the Eq. 8 workspace
-            // and are read through the group index by the aggregation / score kernels (the 37 rows of an impression
-            // share them: they stay in L2); only P' = K3_b + P depends on the row and is expanded.
             const size_t ndg = (size_t)G * U * d;
             const size_t nd = (size_t)B * U * d;
-            float* Xg = Xu[1];                                  // group nodes and P of the groups: free until this
-            float* P0 = Xg + ndg;                               // layer's output is written (2 ndg <= nd)
+            float* P0 = Xu[1] + ndg;
             float* h0 = (float*)xws;
             float* P = h0 + nd;
             float* Q0 = P + nd;
-            {
-                const long total4 = (long)ndg / 4;
-                int blocks = (int)((total4 + 255) / 256);
-                if (blocks > 2048) blocks = 2048;
-                hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue_groups,
-                                   (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
-                DIGAT_CHECK_LAUNCH();
+            if (group_early) {
+                if (hipStreamWaitEvent(st, side->early, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
+            } else {
+                rc = group_project(st);
+                if (rc) return rc;
             }
-            GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
-            gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
-            gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = Q0;
-            gg.nsegs = 3;
-            gg.wsplit = (const unsigned short*)lu.wsplit;
-            gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
-            rc = launch_gemm(gg, st, DIGAT_KERNEL_PROJ);
-            if (rc) return rc;
             float* alpha = (float*)((char*)xws + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
             {
                 const long total4 = (long)nd / 4;
