@@ -291,6 +291,30 @@ def fixture_train_step(ge):
          g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
 
 
+def fixture_msa():
+    """MSA news encoder: the reference's own layers.MultiHeadAttention / layers.Attention modules composed
+    as newsEncoders.MSA.forward composes them (newsEncoders.py:70-82; NewsEncoder.__init__ itself needs the dataset's
+    word-embedding pickle, so the modules are built directly), eval mode."""
+    import layers  # the reference's layers.py (already on sys.path)
+    for tag, (T_, Lw, V, dm, h, dk, att, seed) in {"msa_tiny": (6, 8, 40, 20, 2, 8, 12, 51),
+                                                   "msa_default": (12, 32, 500, 300, 16, 25, 256, 52)}.items():
+        state = synthetic.make_msa_state(V, dm, h, dk, att, seed=seed)
+        text, mask = synthetic.make_titles(T_, Lw, V, seed=seed + 1)
+        mha = layers.MultiHeadAttention(h, dm, Lw, Lw, dk, dk)
+        attn = layers.Attention(h * dk, att)
+        mha.load_state_dict({k[len("multiheadSelfattention."):]: T(v) for k, v in state.items() if k.startswith("multiheadSelfattention.")})
+        attn.load_state_dict({k[len("attention."):]: T(v) for k, v in state.items() if k.startswith("attention.")})
+        with torch.no_grad():
+            w = torch.nn.functional.embedding(T(text), T(state["word_embedding.weight"]))      # newsEncoders.py:76 (dropout off)
+            hfeat = torch.relu(mha(w, w, w))                                                   # :78
+            out = attn(hfeat, mask=T(mask.astype(np.int64)))                                   # :80
+        extra = {}
+        if tag == "msa_tiny":
+            extra = dict(in_title_text=text, in_title_mask=mask, **{"w_" + k: v for k, v in state.items()})
+        save(f"{tag}.npz", meta=np.array([T_, Lw, V, dm, h, dk, att]), seeds=np.array([seed, seed + 1]),
+             input_checksum=checksum({"t": text, "m": mask}, state), out_news_representation=out.numpy(), **extra)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -301,6 +325,7 @@ def main():
     fixture_train_step(ge)
     fixture_devset(ge, ev)
     fixture_default(ge)
+    fixture_msa()
 
 
 if __name__ == "__main__":

@@ -162,3 +162,32 @@ def test_devset_scores_ranks_metrics(name):
     # and end to end from the oracle's own scores: the repo-stated metric tolerance
     got2 = O.ranking_metrics(labels, O.impression_ranks(scores.tolist(), corpus.row_impression.tolist()))
     np.testing.assert_allclose(got2, fx["metrics"], rtol=0, atol=1e-4)
+
+
+# --------------------------------------------------------------------------------------------------
+# MSA news encoder: oracle/news_oracle.py vs vectors minted from the reference's layers.py modules
+# --------------------------------------------------------------------------------------------------
+def _msa_case(name):
+    from digat_amd import synthetic
+    fx = load_golden(name)
+    T_, Lw, V, dm, h, dk, att = (int(v) for v in fx["meta"])
+    s_w, s_t = (int(v) for v in fx["seeds"])
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=s_w)
+    text, mask = synthetic.make_titles(T_, Lw, V, seed=s_t)
+    tot = float(np.asarray(text, dtype=np.float64).sum() + np.asarray(mask, dtype=np.float64).sum())
+    tot += sum(float(np.asarray(v, dtype=np.float64).sum()) for v in state.values())
+    assert abs(tot - float(fx["input_checksum"])) < 1e-6 * max(1.0, abs(tot)), "regenerated MSA inputs differ from the minted ones"
+    if "in_title_text" in fx:
+        assert np.array_equal(fx["in_title_text"], text) and np.array_equal(fx["in_title_mask"], mask)
+    return state, text, mask, h, fx["out_news_representation"]
+
+
+@pytest.mark.parametrize("name", ["msa_tiny.npz", "msa_default.npz"])
+def test_msa_oracle_matches_reference_layers(name):
+    from oracle import news_oracle
+    state, text, mask, h, want = _msa_case(name)
+    p = {k: torch.from_numpy(v) for k, v in state.items()}
+    with torch.no_grad():
+        got = news_oracle.msa_forward(p, torch.from_numpy(text), torch.from_numpy(mask), h).numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
