@@ -24,6 +24,13 @@ class LayerParams(C.Structure):
     _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a", "wsplit")]
 
 
+class MsaParams(C.Structure):
+    """digat_msa_params (include/digat_hip.h)."""
+    _fields_ = ([(k, C.c_int32) for k in ("word_embedding_dim", "head_num", "head_dim", "attention_dim")]
+                + [(k, C.c_void_p) for k in ("word_embedding", "W_Q", "b_Q", "W_K", "W_V", "b_V", "A1", "b1", "a2",
+                                             "qkv_wsplit", "a1_wsplit")])
+
+
 class Params(C.Structure):
     _fields_ = ([("d", C.c_int32), ("depth", C.c_int32), ("category_num", C.c_int32), ("reserved", C.c_int32)]
                 + [(k, _f) for k in ("topic_node_embedding", "cand_K", "cand_Q", "cand_bQ",
@@ -60,6 +67,10 @@ _SIGNATURES = {
     "digat_set_live_row_skipping": (C.c_int, [C.c_int]),
     "digat_profile_live_row_fraction": (C.c_double, []),
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
+    "digat_msa_split_bytes": (C.c_size_t, [C.c_int] * 3),
+    "digat_split_msa_weights": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f, _f]),
+    "digat_msa_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_msa_fwd": (C.c_int, [C.POINTER(MsaParams), _f, _f, _f, C.c_int, C.c_int, _f, C.c_size_t, _f]),
     "digat_encoder_grouped_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd_grouped": (C.c_int, [C.POINTER(Params)] + [_f] * 11 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -835,3 +835,4 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 
 #include "digat_train.inc"
 #include "digat_eval.inc"
+#include "digat_news.inc"

@@ -1,8 +1,8 @@
-"""News encoders: UPSTREAM of the hot path, kept as stock PyTorch-ROCm modules (rocBLAS / MIOpen).
+"""News encoders: UPSTREAM of the hot path.  Stock PyTorch-ROCm modules for training; ``MSA`` in eval mode runs on
+the HIP kernels of ``csrc/digat_news.inc`` (``digat_msa_fwd``).
 
-SURVEY.md §2 marks the reference's ``newsEncoders.py`` / ``layers.py:7-115`` out of scope for the HIP
-work: their output ``[., news_embedding_dim]`` is the graph encoder's input.  They are restated here
-only so that ``Model.forward`` (training) and the news-representation cache of ``compute_scores``
+Their output ``[., news_embedding_dim]`` is the graph encoder's input.  They are restated here
+so that ``Model.forward`` (training) and the news-representation cache of ``compute_scores``
 have a producer with the reference's parameter names (``word_embedding``, ``multiheadSelfattention.
 W_{K,Q,V}``, ``attention.affine{1,2}``, ``conv.conv``) and the same semantics:
 word embedding -> dropout -> MSA (16 heads x 25) + ReLU | Conv1d + ReLU -> additive tanh attention.
@@ -104,9 +104,61 @@ class MSA(NewsEncoder):
         self.attention.initialize()
 
     def forward(self, title_text, title_mask):
+        if not self.training and not torch.is_grad_enabled() and title_text.is_cuda:
+            return self.encode_hip(title_text, title_mask)      # inference: the HIP kernels (digat_msa_fwd)
         w, B, n = self._words(title_text)
         h = F.relu(self.multiheadSelfattention(w))
         return self.attention(h, mask=title_mask.view(B * n, -1)).view(B, n, self.news_embedding_dim)
+
+    # ---- inference on the HIP kernels (digat_news.inc); training stays on the stock modules above
+    def _hip_params(self):
+        from . import _lib
+        ws = [self.word_embedding.weight, self.multiheadSelfattention.W_Q.weight, self.multiheadSelfattention.W_Q.bias,
+              self.multiheadSelfattention.W_K.weight, self.multiheadSelfattention.W_V.weight,
+              self.multiheadSelfattention.W_V.bias, self.attention.affine1.weight, self.attention.affine1.bias,
+              self.attention.affine2.weight]
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        cached = getattr(self, "_hip_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        L = _lib.lib()
+        mha = self.multiheadSelfattention
+        dm, hd, att = self.word_embedding_dim, mha.h * mha.d_k, self.attention.affine1.out_features
+        dev = ws[0].device
+        keep = [w.detach().float().contiguous() for w in ws]
+        P = _lib.MsaParams(word_embedding_dim=dm, head_num=mha.h, head_dim=mha.d_k, attention_dim=att)
+        for name, w in zip(("word_embedding", "W_Q", "b_Q", "W_K", "W_V", "b_V", "A1", "b1", "a2"), keep):
+            setattr(P, name, w.data_ptr())
+        if hd % 80 == 0 and dm % 4 == 0 and dm >= 32:          # the bf16x6 matrix-core path (fp32-grade)
+            qkv = torch.empty(L.digat_msa_split_bytes(dm, mha.h, mha.d_k), dtype=torch.uint8, device=dev)
+            _lib.check(L.digat_split_msa_weights(keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), dm, hd,
+                                                 qkv.data_ptr(), _lib.stream_ptr()), "digat_split_msa_weights")
+            a1 = torch.empty(L.digat_split_weights_bytes(att, hd), dtype=torch.uint8, device=dev)
+            _lib.check(L.digat_split_weights(keep[6].data_ptr(), att, hd, a1.data_ptr(), _lib.stream_ptr()), "digat_split_weights")
+            P.qkv_wsplit, P.a1_wsplit = qkv.data_ptr(), a1.data_ptr()
+            keep += [qkv, a1]
+        self._hip_cache = (key, (P, keep))
+        return P, keep
+
+    def encode_hip(self, title_text, title_mask):
+        """title_text / title_mask [B, n, Lw] (or [T, Lw]) on the GPU -> [B, n, news_embedding_dim] ([T, ...])."""
+        from . import _lib
+        shape = title_text.shape
+        Lw = shape[-1]
+        tok = title_text.reshape(-1, Lw).to(torch.int32).contiguous()
+        msk = (title_mask.reshape(-1, Lw) != 0).to(torch.uint8).contiguous()
+        dev = _lib.require_device(tok, msk)
+        T = tok.shape[0]
+        P, _keep = self._hip_params()
+        out = torch.empty((T, self.news_embedding_dim), dtype=torch.float32, device=dev)
+        if T:
+            L = _lib.lib()
+            mha = self.multiheadSelfattention
+            nbytes = L.digat_msa_workspace_bytes(T, Lw, self.word_embedding_dim, mha.h, mha.d_k, self.attention.affine1.out_features)
+            ws = _lib.workspace(nbytes, dev, "msa")
+            _lib.check(L.digat_msa_fwd(P, tok.data_ptr(), msk.data_ptr(), out.data_ptr(), T, Lw, ws.data_ptr(), nbytes,
+                                       _lib.stream_ptr()), "digat_msa_fwd")
+        return out.view(*shape[:-1], self.news_embedding_dim)
 
 
 class CNN(NewsEncoder):

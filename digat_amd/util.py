@@ -75,6 +75,22 @@ def shard_rows(row_impression: np.ndarray, world_size: int, rank: int) -> Tuple[
     return cut(rank), cut(rank + 1)
 
 
+def cache_news_representations(news_encoder, title_text: torch.Tensor, title_mask: torch.Tensor, batch_size: int) -> torch.Tensor:
+    """util.py:24-33: the representation of every news, computed once per dev/test run in batches.
+    ``title_text`` / ``title_mask`` [news_num, max_title_length] on the GPU.  With ``newsEncoders.MSA`` in eval mode this
+    runs on the HIP kernels (``digat_msa_fwd``: embedding lookup folded into the bf16x6 projection GEMM, attention on the
+    matrix cores)."""
+    news_num = title_text.shape[0]
+    out = torch.empty((news_num, news_encoder.news_embedding_dim), dtype=torch.float32, device=title_text.device)
+    if hasattr(news_encoder, "eval"):
+        news_encoder.eval()
+    with torch.no_grad():
+        for s in range(0, news_num, batch_size):
+            e = min(s + batch_size, news_num)
+            out[s:e] = news_encoder(title_text[s:e].unsqueeze(1), title_mask[s:e].unsqueeze(1)).squeeze(1)   # :30-32
+    return out
+
+
 def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
     """util.py:34-44: gather the SA neighbourhood embeddings and precompute c_n0 for every news."""
     news_num, N = dc.news_node_ID.shape

@@ -257,6 +257,27 @@ int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* strea
 int digat_rank_metrics(const float* scores, const uint8_t* labels, const int64_t* impression_start, int num_impressions,
                        int32_t* ranks, double* per_impression, double* mean4, void* stream);
 
+/* ---- news encoder (upstream of the path): newsEncoders.MSA.forward in eval mode ------------------
+ * newsEncoders.py:70-82 with layers.MultiHeadAttention (layers.py:50-88) and layers.Attention (:91-115).
+ * title_text [T, Lw] int32 token ids (rows of word_embedding), title_mask [T, Lw] bytes (0 = padding: masked only in
+ * the pooling, as in the reference), out [T, head_num * head_dim].  Lw <= 64, head_dim <= 32.
+ * qkv_wsplit: [W_Q|W_K|W_V] split by digat_split_proj_weights-style call digat_split_msa_weights (optional: NULL =
+ * fp32 MFMA path with a materialised embedding gather). */
+typedef struct digat_msa_params {
+    int32_t word_embedding_dim, head_num, head_dim, attention_dim;
+    const float *word_embedding;                 /* word_embedding.weight [V, word_embedding_dim]            */
+    const float *W_Q, *b_Q, *W_K, *W_V, *b_V;    /* multiheadSelfattention.W_{Q,K,V}.{weight,bias}            */
+    const float *A1, *b1, *a2;                   /* attention.affine1.{weight,bias}, attention.affine2.weight */
+    const void  *qkv_wsplit;                     /* digat_split_msa_weights output, or NULL                   */
+    const void  *a1_wsplit;                      /* digat_split_weights(affine1.weight, attention_dim, hd) output, or NULL */
+} digat_msa_params;
+size_t digat_msa_split_bytes(int word_embedding_dim, int head_num, int head_dim);
+int digat_split_msa_weights(const float* W_Q, const float* W_K, const float* W_V, int word_embedding_dim, int hd,
+                            void* wsplit, void* stream);
+size_t digat_msa_workspace_bytes(int T, int Lw, int word_embedding_dim, int head_num, int head_dim, int attention_dim);
+int digat_msa_fwd(const digat_msa_params* params, const int32_t* title_text, const uint8_t* title_mask, float* out,
+                  int T, int Lw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
  * Between start and stop every kernel launch of this library is bracketed by two events recorded
  * on the stream it is launched on.  stop() synchronises and returns, per kernel kind, the summed

@@ -108,6 +108,35 @@ def bench_topic(B=1024, H=50, C=17, d=400):
           f"{by/med/1e6:.0f} GB/s algorithmic ({by/1e6:.0f} MB)")
 
 
+def bench_msa(T=8192, Lw=32, V=30000, dm=300, h=16, dk=25, att=256):
+    import types
+    from digat_amd import newsEncoders, synthetic
+    dev = torch.device("cuda:0")
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=1)
+    text, mask = synthetic.make_titles(T, Lw, V, seed=2)
+    cfg = types.SimpleNamespace(vocabulary_size=V, word_embedding_dim=dm, max_title_length=Lw, dropout_rate=0.2,
+                                MSA_head_num=h, MSA_head_dim=dk, attention_dim=att)
+    enc = newsEncoders.MSA(cfg)
+    enc.load_state_dict({k_: torch.from_numpy(v) for k_, v in state.items()})
+    enc = enc.to(dev).eval()
+    tt, tm = torch.from_numpy(text).to(dev), torch.from_numpy(mask).to(dev)
+
+    def hip():
+        with torch.no_grad():
+            return enc(tt, tm)
+
+    def stock():
+        with torch.enable_grad():           # eval mode + grad enabled = the stock torch modules
+            return enc(tt.unsqueeze(0), tm.unsqueeze(0))
+    a = hip()
+    b = stock().detach()[0]
+    m1, _ = timeit(hip, iters=10)
+    m2, _ = timeit(stock, iters=10)
+    flops = T * Lw * (2.0 * dm * 3 * h * dk + 2.0 * h * dk * att) + T * h * 4.0 * Lw * Lw * dk
+    print(f"MSA news encoder T={T} titles x {Lw} tokens: HIP {m1:.2f} ms ({T/m1/1e3:.2f} M titles/s, {flops/m1/1e9:.1f} TFLOP/s fp32-eq)"
+          f"   stock torch {m2:.2f} ms   max|diff| {float((a - b).abs().max()):.2e}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "xattn"
     nums = [int(v) for v in sys.argv[2:]]
@@ -115,6 +144,8 @@ if __name__ == "__main__":
         bench_xattn(*nums)
     elif what == "xattn-mind":
         bench_xattn(*nums, density="mind")
+    elif what == "msa":
+        bench_msa(*nums)
     elif what == "topic":
         bench_topic(*nums)
     elif what == "linear":
