@@ -12,6 +12,7 @@
 //                      scatter_softmax + scatter_sum over history categories
 //   digat_glue.inc     user-node build, group expansion, live-row lists, row logits
 //   digat_train.inc    backward / training kernels;  digat_eval.inc  per-impression ranking + metrics
+//   digat_news.inc     MSA news encoder (inference);  digat_gat.inc  vanilla-GAT layer of the ablation encoders
 // This file: shared helpers, the per-kernel profiler, and the C ABI (encoder orchestration included).
 //
 // gfx950 only: 64-wide wavefronts, 160 KiB LDS per CU, MFMA f32 16x16x4.  No CUDA shims.
@@ -836,3 +837,4 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 #include "digat_train.inc"
 #include "digat_eval.inc"
 #include "digat_news.inc"
+#include "digat_gat.inc"

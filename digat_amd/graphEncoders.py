@@ -353,3 +353,201 @@ class DIGAT(GraphEncoder):
                   user_category_mask, user_category_indices, news_graph_context):
         return self._encode(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                             user_category_mask, user_category_indices, news_graph_context)
+
+
+# ======================================================================================================
+# the five ablation encoders of the reference (graphEncoders.py:201-842), on the same kernels
+# ======================================================================================================
+class _Ablation(GraphEncoder):
+    """Shared machinery.  A subclass names which graph runs Eq. 8 (``EQ8``), which runs the vanilla-GAT layer (``GAT``)
+    and whether the news context exists (``NEWS_CONTEXT``); parameter names are the reference's, so its checkpoints
+    load.  Inference / eval-mode forward run on the HIP kernels (``digat_xattn_fwd``, ``digat_gat_fwd``,
+    ``digat_news_ctx_fwd``, ``digat_user_ctx_fwd``); training these variants is not implemented natively."""
+    EQ8: tuple = ()
+    GAT: tuple = ()
+    NEWS_CONTEXT = True
+
+    def __init__(self, config, news_embedding_dim: int):
+        super().__init__(config, news_embedding_dim)
+        d, L = self.news_embedding_dim, self.graph_depth
+        if d % 4 != 0:
+            raise ValueError("digat_amd needs news_embedding_dim % 4 == 0 (float4 rows)")
+        if self.NEWS_CONTEXT:
+            self.candidate_attention = ScaledDotProductAttention(d, d, d)
+            self.news_graph_W = nn.Linear(d * 2, d, bias=True)
+        self.user_news_K = nn.Linear(d, d, bias=False)
+        self.user_news_Q = nn.Linear(d, d, bias=True)
+        self.featureAffine = nn.Linear(d, d, bias=True)
+        self.userAttention = ScaledDotProductAttention(d, d, d)
+        for g in self.EQ8:
+            setattr(self, f"{g}_graph_attention_W", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn1", nn.ModuleList([nn.Linear(d, d, bias=False) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn2", nn.ModuleList([nn.Linear(d, d, bias=False) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_ffn3", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_a", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
+        for g in self.GAT:
+            setattr(self, f"{g}_graph_attention_W", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_a1", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
+            setattr(self, f"{g}_graph_attention_a2", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
+
+    def initialize(self):
+        super().initialize()
+        relu_gain = nn.init.calculate_gain('relu')
+        leaky_gain = nn.init.calculate_gain('leaky_relu', 0.2)
+        for g in self.EQ8 + self.GAT:
+            for i in range(self.graph_depth):
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_W")[i].weight)
+                nn.init.zeros_(getattr(self, f"{g}_graph_attention_W")[i].bias)
+        for g in self.EQ8:
+            for i in range(self.graph_depth):
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_a")[i].weight, gain=leaky_gain)
+                for f in ("ffn1", "ffn2", "ffn3"):
+                    nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_{f}")[i].weight, gain=relu_gain)
+                nn.init.zeros_(getattr(self, f"{g}_graph_attention_ffn3")[i].bias)
+        for g in self.GAT:
+            for i in range(self.graph_depth):
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_a1")[i].weight, gain=leaky_gain)
+                nn.init.xavier_uniform_(getattr(self, f"{g}_graph_attention_a2")[i].weight, gain=leaky_gain)
+        if self.NEWS_CONTEXT:
+            self.candidate_attention.initialize()
+            nn.init.xavier_uniform_(self.news_graph_W.weight)
+            nn.init.zeros_(self.news_graph_W.bias)
+        nn.init.xavier_uniform_(self.user_news_K.weight)
+        nn.init.xavier_uniform_(self.user_news_Q.weight)
+        nn.init.zeros_(self.user_news_Q.bias)
+        nn.init.xavier_uniform_(self.featureAffine.weight, gain=relu_gain)
+        nn.init.zeros_(self.featureAffine.bias)
+        self.userAttention.initialize()
+
+    # the context functions and the Eq. 8 layer are DIGAT's (same attribute names)
+    _eval_only = DIGAT._eval_only
+    compute_news_graph_context = DIGAT.compute_news_graph_context
+    compute_user_graph_context = DIGAT.compute_user_graph_context
+    _xattn = DIGAT._xattn
+
+    def _gat(self, g: str, index: int, X, A):
+        """Vanilla GAT update layer (graphEncoders.py:493-519)."""
+        self._eval_only("vanilla GAT layer")
+        X = _lib.f32(X)
+        dev = _lib.require_device(X, A)
+        B, n, d = X.shape
+        out = torch.empty_like(X)
+        if B == 0:
+            return out
+        adj = _lib.as_bytes(A)
+        L = _lib.lib()
+        nbytes = L.digat_gat_workspace_bytes(B, n, d)
+        ws = _lib.workspace(nbytes, dev, "gat")
+        W = getattr(self, f"{g}_graph_attention_W")[index]
+        _lib.check(L.digat_gat_fwd(X.data_ptr(), adj.data_ptr(), W.weight.data_ptr(), W.bias.data_ptr(),
+                                   getattr(self, f"{g}_graph_attention_a1")[index].weight.data_ptr(),
+                                   getattr(self, f"{g}_graph_attention_a2")[index].weight.data_ptr(), out.data_ptr(), B, n, d,
+                                   ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_gat_fwd")
+        return out
+
+    def _user_nodes(self, user_news_embedding):
+        ue = _lib.f32(user_news_embedding)
+        return torch.cat([ue, self.topic_node_embedding.unsqueeze(0).expand(ue.shape[0], -1, -1)], dim=1).contiguous()
+
+    def _layer(self, g: str, i: int, X, A, ctx):
+        if g in self.EQ8:
+            self._eval_only("Eq. 8 layer")
+            return self._xattn(g, i, X, A, ctx)
+        return self._gat(g, i, X, A)
+
+    def _encode(self, Xn, An, Mn, ue, Au, cm, ci, c_n):
+        Xu = self._user_nodes(ue)
+        c_u = self.compute_user_graph_context(Xu, cm, ci, c_n)
+        for i in range(self.graph_depth):
+            # both updates read the PREVIOUS contexts; tuple assignment keeps the reference's order of evaluation
+            Xn, Xu = self._layer("news", i, Xn, An, c_u), self._layer("user", i, Xu, Au, c_n)
+            c_n = c_n + self.compute_news_graph_context(Xn, Mn)
+            c_u = c_u + self.compute_user_graph_context(Xu, cm, ci, c_n)
+        return c_n, c_u
+
+    def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                user_category_mask, user_category_indices):
+        self._eval_only(type(self).__name__ + ".forward")
+        c_n = self.compute_news_graph_context(news_graph_embeddings, news_graph_mask)
+        return self._encode(_lib.f32(news_graph_embeddings), news_graph, news_graph_mask, user_news_embedding, user_graph,
+                            user_category_mask, user_category_indices, c_n)
+
+    def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                  user_category_mask, user_category_indices, news_graph_context):
+        return self._encode(_lib.f32(news_graph_embeddings), news_graph, news_graph_mask, user_news_embedding, user_graph,
+                            user_category_mask, user_category_indices, _lib.f32(news_graph_context))
+
+
+class wo_SA(_Ablation):
+    """graphEncoders.py:201-293 — no semantic-augmentation graph: the candidate's own representation is the context."""
+    EQ8, GAT, NEWS_CONTEXT = ("user",), (), False
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph, news_graph_context):
+        return self._layer("user", index, user_graph_embeddings, user_graph, news_graph_context)
+
+    def _run(self, news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices):
+        c = _lib.f32(news_graph_embeddings)[:, 0].contiguous()
+        Xu = self._user_nodes(user_news_embedding)
+        for i in range(self.graph_depth):
+            Xu = self._layer("user", i, Xu, user_graph, c)
+        return c, self.compute_user_graph_context(Xu, user_category_mask, user_category_indices, c)
+
+    def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                user_category_mask, user_category_indices):
+        return self._run(news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices)
+
+    def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                  user_category_mask, user_category_indices, news_graph_context):
+        return self._run(news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices)
+
+
+class Seq_SA(_Ablation):
+    """graphEncoders.py:295-408 — the neighbourhood as a sequence: pooled once into the news context, never updated."""
+    EQ8, GAT = ("user",), ()
+
+    def compute_news_sequence_context(self, news_graph_embeddings, news_graph_mask):
+        return self.compute_news_graph_context(news_graph_embeddings, news_graph_mask)
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph, news_graph_context):
+        return self._layer("user", index, user_graph_embeddings, user_graph, news_graph_context)
+
+    def _encode(self, Xn, An, Mn, ue, Au, cm, ci, c_n):
+        Xu = self._user_nodes(ue)
+        c_u = self.compute_user_graph_context(Xu, cm, ci, c_n)
+        for i in range(self.graph_depth):
+            Xu = self._layer("user", i, Xu, Au, c_n)
+            c_u = c_u + self.compute_user_graph_context(Xu, cm, ci, c_n)
+        return c_n, c_u
+
+
+class wo_interaction(_Ablation):
+    """graphEncoders.py:410-549 — vanilla GAT layers on both graphs."""
+    EQ8, GAT = (), ("news", "user")
+
+    def compute_news_graph_embeddings(self, index, news_graph_embeddings, news_graph):
+        return self._gat("news", index, news_graph_embeddings, news_graph)
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph):
+        return self._gat("user", index, user_graph_embeddings, user_graph)
+
+
+class News_graph_wo_inter(_Ablation):
+    """graphEncoders.py:551-696 — vanilla GAT on the news graph, Eq. 8 on the user graph."""
+    EQ8, GAT = ("user",), ("news",)
+
+    def compute_news_graph_embeddings(self, index, news_graph_embeddings, news_graph):
+        return self._gat("news", index, news_graph_embeddings, news_graph)
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph, news_graph_context):
+        return self._layer("user", index, user_graph_embeddings, user_graph, news_graph_context)
+
+
+class User_graph_wo_inter(_Ablation):
+    """graphEncoders.py:698-842 — Eq. 8 on the news graph, vanilla GAT on the user graph."""
+    EQ8, GAT = ("news",), ("user",)
+
+    def compute_news_graph_embeddings(self, index, news_graph_embeddings, news_graph, user_graph_context):
+        return self._layer("news", index, news_graph_embeddings, news_graph, user_graph_context)
+
+    def compute_user_graph_embeddings(self, index, user_graph_embeddings, user_graph):
+        return self._gat("user", index, user_graph_embeddings, user_graph)

@@ -2,8 +2,8 @@
 
 ``config.graph_encoder == 'DIGAT'`` selects the HIP plugin (model.py:18-19); ``forward`` (9 tensors,
 training) and ``inference`` (8 tensors, dev/test) keep the reference's signatures and reshapes
-(model.py:54-90).  The five ablation encoders are not built and raise the same
-``'<name> is not implemented'`` exception the reference raises for unknown names.
+(model.py:54-90).  The five ablation encoders run on the same kernels in eval mode /
+inference; unknown names raise the reference's ``'<name> is not implemented'`` exception.
 """
 from __future__ import annotations
 
@@ -24,8 +24,11 @@ class Model(nn.Module):
             self.news_encoder = newsEncoders.MSA(config)
         else:
             raise Exception(config.news_encoder + ' is not implemented')
-        if config.graph_encoder == 'DIGAT':
-            self.graph_encoder = graphEncoders.DIGAT(config, self.news_encoder.news_embedding_dim)
+        variants = {'DIGAT': graphEncoders.DIGAT, 'wo_SA': graphEncoders.wo_SA, 'Seq_SA': graphEncoders.Seq_SA,
+                    'wo_interaction': graphEncoders.wo_interaction, 'news_graph_wo_inter': graphEncoders.News_graph_wo_inter,
+                    'user_graph_wo_inter': graphEncoders.User_graph_wo_inter}       # model.py:18-31
+        if config.graph_encoder in variants:
+            self.graph_encoder = variants[config.graph_encoder](config, self.news_encoder.news_embedding_dim)
         else:
             raise Exception(config.graph_encoder + ' is not implemented')
         self.model_name = str(getattr(config, 'news_encoder', 'MSA')) + '-' + config.graph_encoder

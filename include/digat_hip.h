@@ -257,6 +257,14 @@ int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* strea
 int digat_rank_metrics(const float* scores, const uint8_t* labels, const int64_t* impression_start, int num_impressions,
                        int32_t* ranks, double* per_impression, double* mean4, void* stream);
 
+/* ---- vanilla-GAT update layer of the ablation encoders -----------------------------------------
+ * graphEncoders.py:493-519 (wo_interaction), :641-651 (News_graph_wo_inter), :788-798 (User_graph_wo_inter), eval mode:
+ * h = X W^T + bW; e_ij = leaky_relu_0.2(a1.h_j + a2.h_i); -1e9 where A_ij = 0; alpha = softmax_j; out = relu(alpha h) + X.
+ * X, out [B,n,d]; A [B,n,n] bytes; W [d,d], bW [d] or NULL, a1, a2 [d]. */
+size_t digat_gat_workspace_bytes(int B, int n, int d);
+int digat_gat_fwd(const float* X, const uint8_t* A, const float* W, const float* bW, const float* a1, const float* a2,
+                  float* out, int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- news encoder (upstream of the path): newsEncoders.MSA.forward in eval mode ------------------
  * newsEncoders.py:70-82 with layers.MultiHeadAttention (layers.py:50-88) and layers.Attention (:91-115).
  * title_text [T, Lw] int32 token ids (rows of word_embedding), title_mask [T, Lw] bytes (0 = padding: masked only in

@@ -269,6 +269,55 @@ def ranking_metrics(labels: List[List[int]], ranks: List[List[int]]):
 
 
 # ------------------------------------------------------------------------------------------
+# the five ablation encoders (graphEncoders.py:201-842), eval mode
+# ------------------------------------------------------------------------------------------
+ABLATIONS = ("wo_SA", "Seq_SA", "wo_interaction", "News_graph_wo_inter", "User_graph_wo_inter")
+
+
+def gat_layer(p: Params, graph: str, layer: int, X: torch.Tensor, adj: torch.Tensor) -> torch.Tensor:
+    """Vanilla GAT update (graphEncoders.py:493-503 / :510-519): e_ij = leaky_relu(a1.h_j + a2.h_i)."""
+    B, n, _ = X.shape
+    pre = f"{graph}_graph_attention_"
+    h = _linear(X, p, f"{pre}W.{layer}")
+    a1 = F.linear(h, p[f"{pre}a1.{layer}.weight"]).view(B, 1, n)               # over the neighbour j
+    a2 = F.linear(h, p[f"{pre}a2.{layer}.weight"])                             # [B,n,1]: over the centre i
+    e = F.leaky_relu(a1 + a2, 0.2)
+    alpha = F.softmax(e.masked_fill(adj == 0, MASK_FILL), dim=2)
+    return F.relu(torch.bmm(alpha, h)) + X
+
+
+def ablation_encode(name: str, p: Params, depth: int, Xn, An, Mn, user_news_embedding, Au, cat_mask, cat_idx, c_n=None):
+    """``forward`` (c_n None: computed here where the class computes it) / ``inference`` (c_n given) of an ablation
+    encoder, eval mode.  Returns (news context, user context)."""
+    assert name in ABLATIONS
+    H = user_news_embedding.shape[1]
+    Xu = user_nodes(p, user_news_embedding)
+    if name == "wo_SA":                                   # :276-293 — no news graph; context = the candidate itself
+        c = Xn[:, 0]
+        for i in range(depth):
+            Xu = cross_graph_attention(p, "user", i, Xu, Au, c)
+        return c, user_graph_context(p, Xu, cat_mask, cat_idx, c, H)
+    if c_n is None:
+        c_n = news_graph_context(p, Xn, Mn)               # compute_news_{graph,sequence}_context
+    c_u = user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H)
+    for i in range(depth):
+        if name == "Seq_SA":                              # :390-408 — the neighbourhood is a sequence: pooled once, never updated
+            Xu = cross_graph_attention(p, "user", i, Xu, Au, c_n)
+            c_u = c_u + user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H)
+            continue
+        if name == "wo_interaction":                      # :523-549
+            Xn_next, Xu_next = gat_layer(p, "news", i, Xn, An), gat_layer(p, "user", i, Xu, Au)
+        elif name == "News_graph_wo_inter":               # :672-696
+            Xn_next, Xu_next = gat_layer(p, "news", i, Xn, An), cross_graph_attention(p, "user", i, Xu, Au, c_n)
+        else:                                             # User_graph_wo_inter :819-842
+            Xn_next, Xu_next = cross_graph_attention(p, "news", i, Xn, An, c_u), gat_layer(p, "user", i, Xu, Au)
+        Xn, Xu = Xn_next, Xu_next
+        c_n = c_n + news_graph_context(p, Xn, Mn)
+        c_u = c_u + user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H)
+    return c_n, c_u
+
+
+# ------------------------------------------------------------------------------------------
 # convenience for tests / bench: numpy in, numpy out
 # ------------------------------------------------------------------------------------------
 def _t(x):

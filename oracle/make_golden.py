@@ -291,6 +291,36 @@ def fixture_train_step(ge):
          g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
 
 
+def fixture_ablations(ge):
+    """the five ablation encoders (graphEncoders.py:201-842), eval-mode forward and inference, at the tiny
+    shapes (inputs stored) and at the default shapes (inputs and weights regenerate from seeds).  Loading the
+    generated state dict with strict=True pins the parameter names of every class."""
+    for name in ("wo_SA", "Seq_SA", "wo_interaction", "News_graph_wo_inter", "User_graph_wo_inter"):
+        for tag, (B, N, H, C, d, L, seed) in {"tiny": (4, 4, 10, 5, 64, 2, 81), "default": (6, 10, 50, 17, 400, 3, 83)}.items():
+            state = synthetic.make_ablation_state_dict(name, d, C, L, seed=seed)
+            batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=seed + 1, empty_history_rows=(1,), isolated_news_rows=(2,))
+            cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C, graph_depth=L, dropout_rate=0.0)
+            enc = getattr(ge, name)(cfg, d)
+            enc.initialize()
+            missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+            assert not missing.missing_keys and not missing.unexpected_keys
+            enc.eval()
+            b = {k: T(v) for k, v in batch.items()}
+            args = (b["news_graph_embeddings"], b["news_graph"], b["news_graph_mask"], b["user_news_embedding"], b["user_graph"],
+                    b["user_category_mask"], b["user_category_indices"])
+            with torch.no_grad():
+                fn, fu = enc(*args)
+                c0 = fn if name == "wo_SA" else (enc.compute_news_sequence_context if name == "Seq_SA"
+                                                  else enc.compute_news_graph_context)(args[0], args[2])
+                inn, inu = enc.inference(*args, c0)
+            extra = {}
+            if tag == "tiny" and name == "wo_interaction":      # one class keeps its inputs and weights on disk as well
+                extra = dict(**{"in_" + k: v for k, v in batch.items()}, **{"w_" + k: v for k, v in state.items()})
+            save(f"ablation_{name}_{tag}.npz", meta=np.array([B, N, H, C, d, L]), seeds=np.array([seed, seed + 1]),
+                 input_checksum=checksum(batch, state), out_forward_news=fn.numpy(), out_forward_user=fu.numpy(),
+                 out_inference_news=inn.numpy(), out_inference_user=inu.numpy(), **extra)
+
+
 def fixture_msa():
     """MSA news encoder: the reference's own layers.MultiHeadAttention / layers.Attention modules composed
     as newsEncoders.MSA.forward composes them (newsEncoders.py:70-82; NewsEncoder.__init__ itself needs the dataset's
@@ -325,6 +355,7 @@ def main():
     fixture_train_step(ge)
     fixture_devset(ge, ev)
     fixture_default(ge)
+    fixture_ablations(ge)
     fixture_msa()
 
 

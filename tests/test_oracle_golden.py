@@ -191,3 +191,34 @@ def test_msa_oracle_matches_reference_layers(name):
         got = news_oracle.msa_forward(p, torch.from_numpy(text), torch.from_numpy(mask), h).numpy()
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------------
+# the five ablation encoders — oracle vs vectors minted from the reference's classes
+# --------------------------------------------------------------------------------------------------
+def _ablation_case(name, tag):
+    from digat_amd import synthetic
+    fx = load_golden(f"ablation_{name}_{tag}.npz")
+    B, N, H, C, d, L = (int(v) for v in fx["meta"])
+    s_w, s_b = (int(v) for v in fx["seeds"])
+    state = synthetic.make_ablation_state_dict(name, d, C, L, seed=s_w)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=s_b, empty_history_rows=(1,), isolated_news_rows=(2,))
+    tot = sum(float(np.asarray(v, dtype=np.float64).sum()) for v in list(batch.values()) + list(state.values()))
+    assert abs(tot - float(fx["input_checksum"])) < 1e-6 * max(1.0, abs(tot)), "regenerated inputs differ from the minted ones"
+    return fx, state, batch, L
+
+
+@pytest.mark.parametrize("tag", ["tiny", "default"])
+@pytest.mark.parametrize("name", list(O.ABLATIONS))
+def test_ablation_oracle_matches_reference(name, tag):
+    fx, state, batch, L = _ablation_case(name, tag)
+    p = O.as_params(state)
+    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    args = (b["news_graph_embeddings"], b["news_graph"], b["news_graph_mask"], b["user_news_embedding"], b["user_graph"],
+            b["user_category_mask"], b["user_category_indices"])
+    with torch.no_grad():
+        fn, fu = O.ablation_encode(name, p, L, *args)
+        c0 = args[0][:, 0] if name == "wo_SA" else O.news_graph_context(p, args[0], args[2])
+        inn, inu = O.ablation_encode(name, p, L, *args, c_n=c0)
+    for got, key in ((fn, "out_forward_news"), (fu, "out_forward_user"), (inn, "out_inference_news"), (inu, "out_inference_user")):
+        np.testing.assert_allclose(got.numpy(), fx[key], rtol=1e-5, atol=ATOL, err_msg=f"{name}/{tag}/{key}")
