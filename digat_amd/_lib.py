@@ -64,6 +64,7 @@ _SIGNATURES = {
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
     "digat_set_side_stream": (C.c_int, [C.c_int]),
+    "digat_profile_pause": (C.c_int, [C.c_int]),
     "digat_set_live_row_skipping": (C.c_int, [C.c_int]),
     "digat_profile_live_row_fraction": (C.c_double, []),
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),

@@ -771,6 +771,14 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
 static double g_prof_last_live_fraction = -1.0;
 double digat_profile_live_row_fraction(void) { return g_prof_last_live_fraction; }
 
+// recording costs two hipEventRecord calls per launch on the host: a caller that wants per-kernel times over a long
+// region without slowing it down samples it — pause(1) ... pause(0) around the steps it does not want recorded
+int digat_profile_pause(int paused) {
+    if (!g_prof.ev) return DIGAT_ERR_ARG;
+    g_prof.enabled = paused ? 0 : 1;
+    return DIGAT_OK;
+}
+
 int digat_profile_start(int max_launches) {
     if (max_launches <= 0) return DIGAT_ERR_ARG;
     if (g_prof.ev) return DIGAT_ERR_ARG;          // already running

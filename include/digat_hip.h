@@ -302,6 +302,7 @@ enum {
     DIGAT_KERNEL_KINDS = 7
 };
 int digat_profile_start(int max_launches);
+int digat_profile_pause(int paused);   /* between start and stop: 1 = launches are not recorded, 0 = recorded again (sampling) */
 /* after digat_profile_stop: rows processed / rows nominal over the row-list node-projection launches of the profiled
  * region (the encoder leaves the user-graph nodes that cannot reach its outputs out of the projections of
  * layers >= 1), or -1 if there was none */
