@@ -8,7 +8,7 @@ identical to ``sklearn.metrics.roc_auc_score`` on these inputs).
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 import numpy as np
 

@@ -12,7 +12,6 @@ indexed into the device-resident synthetic corpus (no DataLoader workers: a batc
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import numpy as np

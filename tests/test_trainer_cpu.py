@@ -2,7 +2,6 @@
 loss — against the reference's rules (trainer.py:25-32,81,100; MIND_dataset.py:26-47)."""
 import types
 
-import numpy as np
 import torch
 
 from digat_amd import synthetic

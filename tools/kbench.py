@@ -8,7 +8,6 @@ Timing with torch events on the current stream, median of --iters launches.
 """
 import os
 import sys
-import time
 
 import torch
 
