@@ -35,7 +35,6 @@ def bench_xattn(B=1024, n=67, d=400, density=None):
     r = torch.randn(B, d, device=dev, generator=g)
     a = torch.randn(d, device=dev, generator=g) * 0.1
     if density == "mind":
-        import numpy as np
         from digat_amd import synthetic
         batch = synthetic.make_encoder_batch(B, 10, 50, n - 50, d, seed=0)
         A = torch.from_numpy(batch["user_graph"]).to(dev).view(torch.uint8)
