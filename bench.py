@@ -86,12 +86,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook (one-GPU boxes): DIGAT_BENCH_TEST_SHARED_GPU=1 puts every rank on cuda:0 and runs the control-plane
+    # collectives (barrier, max / sum of three scalars) over gloo; the data path has no collective either way
+    shared_gpu = os.environ.get("DIGAT_BENCH_TEST_SHARED_GPU") == "1"
+    device_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    ctl_dev = torch.device("cpu") if shared_gpu else dev       # where the timing scalars are reduced
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL on ROCm
+        dist.init_process_group("gloo" if shared_gpu else "nccl")          # nccl = RCCL on ROCm
 
     from digat_amd import _lib, synthetic, util
     from digat_amd.model import Model, PrecomputedNewsEncoder
@@ -178,10 +183,10 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rows_done, corpus.rows, spec.impressions], dtype=torch.float64, device=dev)
+        r = torch.tensor([rows_done, corpus.rows, spec.impressions], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rows_total = float(r[0].item())
         mean_cand = float(r[1].item()) / float(r[2].item())      # candidates per impression over every rank's shard
