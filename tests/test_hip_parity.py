@@ -316,8 +316,8 @@ def test_grouped_inference_is_bit_identical_to_per_row():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18)],
-                         ids=["default", "stress-N65-L7", "large-N26"])
+@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18), (3, 2, 1, 17)],
+                         ids=["default", "stress-N65-L7", "large-N26", "depth1"])
 def test_side_stream_schedule_is_bit_identical_to_single_stream(neighbors, hops, L, cats):
     """The news-graph chain on the side stream (default) vs everything on the caller's stream."""
     from digat_amd import synthetic, util, _lib
@@ -369,8 +369,8 @@ def test_device_ranks_and_metrics_match_host(seed, impressions, max_c, quant):
     assert np.array_equal(only_r, want_r) and none_m is None
 
 
-@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18)],
-                         ids=["default", "stress-N65-L7", "large-N26"])
+@pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18), (3, 2, 1, 17), (3, 2, 2, 17)],
+                         ids=["default", "stress-N65-L7", "large-N26", "depth1", "depth2"])
 def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     """Projections restricted to the live user-graph nodes (default) vs every node: same scores, bit for bit.
     The corpus has empty-history users (every category masked: padding slots are live there) and long histories."""
