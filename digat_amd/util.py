@@ -136,18 +136,120 @@ def gather_batch_grouped(dc: DeviceCorpus, start: int, end: int, row_impression_
             dc.news_graph.index_select(0, cand), dc.news_graph_mask.index_select(0, cand), dc.c_n0.index_select(0, cand))
 
 
+class GroupedBatchPipeline:
+    """Assembles the grouped inputs of batch k+1 on a side stream while batch k is being scored.
+
+    The gathers of a batch are ~10 small kernels (60 us) that would otherwise sit between two encoder calls on the
+    same stream.  ``batches`` lists the (start, end) row ranges in the order they will be taken.  The group structure
+    of every batch (unique impressions, row -> group index) is computed once on the host and uploaded once; two sets
+    of static buffers (user side sized for batch_size // 4 groups, the most the grouped entry takes) alternate, and
+    events order gather -> score -> gather on each set."""
+
+    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray):
+        self.dc, self.batches = dc, list(batches)
+        dev = dc.news_embedding.device
+        self.dev = dev
+        B = max(e - s for s, e in self.batches)
+        Gmax = max(1, B // 4)
+        H, d = dc.history.shape[1], dc.news_embedding.shape[1]
+        U, C1 = dc.user_graph.shape[1], dc.user_category_mask.shape[1]
+        N = dc.news_graph.shape[1]
+
+        def bufs():
+            return dict(hist=torch.empty((Gmax, H), dtype=torch.int64, device=dev),
+                        user_rep=torch.empty((Gmax, H, d), dtype=torch.float32, device=dev),
+                        user_graph=torch.empty((Gmax, U, U), dtype=dc.user_graph.dtype, device=dev),
+                        cat_mask=torch.empty((Gmax, C1), dtype=dc.user_category_mask.dtype, device=dev),
+                        cat_idx=torch.empty((Gmax, H), dtype=torch.int64, device=dev),
+                        sa=torch.empty((B, N, d), dtype=torch.float32, device=dev),
+                        news_graph=torch.empty((B, N, N), dtype=dc.news_graph.dtype, device=dev),
+                        news_mask=torch.empty((B, N), dtype=dc.news_graph_mask.dtype, device=dev),
+                        c_n0=torch.empty((B, d), dtype=torch.float32, device=dev))
+        self.sets = [bufs(), bufs()]
+        uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
+        for s, e in self.batches:
+            imp_b = row_impression_host[s:e]
+            first = np.r_[True, imp_b[1:] != imp_b[:-1]]
+            uniq_parts.append(imp_b[first].astype(np.int64))
+            rg_parts.append((np.cumsum(first) - 1).astype(np.int32))
+            self.uo.append(self.uo[-1] + int(first.sum()))
+            self.ro.append(self.ro[-1] + (e - s))
+        self.uniq_all = torch.from_numpy(np.concatenate(uniq_parts)).to(dev)
+        self.row_group_all = torch.from_numpy(np.concatenate(rg_parts)).to(dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))       # the corpus tables and the index arrays above
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.done = [None, None]
+        self.meta = [None, None]
+        self._gather(0)
+
+    def _gather(self, k):
+        if k >= len(self.batches):
+            return
+        s, e = self.batches[k]
+        par = k & 1
+        G, n = self.uo[k + 1] - self.uo[k], e - s
+        if 4 * G > n:                             # too few rows per group for the grouped entry: per-row path
+            self.meta[par] = (k, None)
+            return
+        dc, b = self.dc, self.sets[par]
+        uniq = self.uniq_all[self.uo[k]:self.uo[k + 1]]
+        if self.done[par] is not None:
+            self.stream.wait_event(self.done[par])                    # this set's previous batch has been scored
+        with torch.cuda.stream(self.stream):
+            cand = dc.row_candidate[s:e]
+            H, d = dc.history.shape[1], dc.news_embedding.shape[1]
+            torch.index_select(dc.history, 0, uniq, out=b["hist"][:G])
+            torch.index_select(dc.news_embedding, 0, b["hist"][:G].reshape(-1), out=b["user_rep"][:G].view(G * H, d))
+            torch.index_select(dc.user_graph, 0, uniq, out=b["user_graph"][:G])
+            torch.index_select(dc.user_category_mask, 0, uniq, out=b["cat_mask"][:G])
+            torch.index_select(dc.user_category_indices, 0, uniq, out=b["cat_idx"][:G])
+            torch.index_select(dc.SA_news_representations, 0, cand, out=b["sa"][:n])
+            torch.index_select(dc.news_graph, 0, cand, out=b["news_graph"][:n])
+            torch.index_select(dc.news_graph_mask, 0, cand, out=b["news_mask"][:n])
+            torch.index_select(dc.c_n0, 0, cand, out=b["c_n0"][:n])
+            self.ready[par].record(self.stream)
+        self.meta[par] = (k, (G, n, self.row_group_all[self.ro[k]:self.ro[k + 1]]))
+
+    def take(self, k):
+        """The 9 inputs of ``Model.inference_grouped`` for batch k, or None (use ``gather_batch`` + ``inference``)."""
+        par = k & 1
+        assert self.meta[par] is not None and self.meta[par][0] == k, "batches must be taken in order"
+        info = self.meta[par][1]
+        if info is None:
+            return None
+        G, n, row_group = info
+        b = self.sets[par]
+        torch.cuda.current_stream(self.dev).wait_event(self.ready[par])
+        return (b["user_rep"][:G], b["user_graph"][:G], b["cat_mask"][:G], b["cat_idx"][:G], row_group,
+                b["sa"][:n], b["news_graph"][:n], b["news_mask"][:n], b["c_n0"][:n])
+
+    def scored(self, k):
+        """Call once batch k's kernels are enqueued: the other buffer set may then be refilled for batch k+1."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.done[k & 1] = ev
+        self._gather(k + 1)
+
+
 def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
     tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``."""
     scores = torch.empty(end - start, dtype=torch.float32, device=dc.news_embedding.device)
     grouped = grouped and hasattr(model, "inference_grouped")
-    imp_host = dc.row_impression.cpu().numpy() if grouped else None
+    batches = [(s, min(s + batch_size, end)) for s in range(start, end, batch_size)]
     with torch.no_grad():
-        for s in range(start, end, batch_size):
-            e = min(s + batch_size, end)
-            if grouped:
-                scores[s - start:e - start] = model.inference_grouped(*gather_batch_grouped(dc, s, e, imp_host))
-            else:
+        if grouped and batches:
+            pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy())
+            for k, (s, e) in enumerate(batches):
+                inputs = pipe.take(k)
+                if inputs is not None:
+                    scores[s - start:e - start] = model.inference_grouped(*inputs)
+                else:
+                    scores[s - start:e - start] = model.inference(*gather_batch(dc, s, e))
+                pipe.scored(k)
+        else:
+            for s, e in batches:
                 scores[s - start:e - start] = model.inference(*gather_batch(dc, s, e))
     return scores
 

@@ -63,3 +63,17 @@ for i in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"gather only: host {1e3*(t1-t0)/K:.3f} ms/step")
+
+# upper bound of what overlapping the gathers with the previous batch could buy: inputs gathered beforehand
+pre = [util.gather_batch_grouped(dc, (i % nb) * B, (i % nb) * B + B, imp) for i in range(nb)]
+torch.cuda.synchronize()
+for i in range(10):
+    with torch.no_grad():
+        model.inference_grouped(*pre[i % nb])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(K):
+    with torch.no_grad():
+        model.inference_grouped(*pre[(5 + i) % nb])
+torch.cuda.synchronize()
+print(f"inference only (inputs pre-gathered): {1e3*(time.perf_counter()-t0)/K:.3f} ms/step")
