@@ -174,7 +174,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
-    return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st, listed ? live : nullptr);
+    return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st, listed ? live : nullptr, nullptr, nullptr,
+                                 alpha_out != nullptr);
 }
 
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
@@ -577,7 +578,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             const size_t ndn = (size_t)B * N * d;
             float* hn = (float*)xws_news;
             float* alpha_n = (float*)((char*)xws_news + align_up(3 * ndn * 4, 256) + align_up((size_t)B * d * 4, 256));
-            rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news);
+            rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
+                                       false);
         } else {
             rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
         }
