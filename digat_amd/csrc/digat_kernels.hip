@@ -435,22 +435,26 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     const int* rowidx = nullptr;
     const int* nrows_dev = nullptr;
     uint8_t* live_flags = nullptr;
-    auto find_live_rows = [&](hipStream_t sq) -> int {     // needed after layer 0's Eq. 8: runs beside it
+    // launches the list kernels on `sq`; `publish` hands the lists to the code below (the initial user context, issued on
+    // the caller's stream at the same time, must not see them: only a join orders the caller's stream after the side stream)
+    const int *pend_rowidx = nullptr, *pend_nrows = nullptr, *pend_bidx = nullptr, *pend_nb = nullptr;
+    uint8_t* pend_flags = nullptr;
+    auto find_live_rows = [&](hipStream_t sq) -> int {
         int* cnt = live_ws;
         int* off = cnt + align_up((size_t)B, 64);
         int* idx = off + align_up((size_t)B + 1, 64);
         int* cnt2 = idx + align_up((size_t)B * U, 64);
         int* off2 = cnt2 + align_up((size_t)B, 64);
         int* idx2 = off2 + align_up((size_t)B + 1, 64);
-        live_flags = (uint8_t*)(idx2 + align_up((size_t)B * C1, 64));
-        uint8_t* flags2 = live_flags + align_up((size_t)B * U, 256);
+        uint8_t* flags1 = (uint8_t*)(idx2 + align_up((size_t)B * C1, 64));
+        uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           live_flags, cnt);
+                           flags1, cnt);
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt, off, B);
         DIGAT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)live_flags, (const int*)off, B, U, idx);
+        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags1, (const int*)off, B, U, idx);
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(bucket_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, cat_mask, B, C1, flags2, cnt2);
         DIGAT_CHECK_LAUNCH();
@@ -458,9 +462,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags2, (const int*)off2, B, C1, idx2);
         DIGAT_CHECK_LAUNCH();
-        rowidx = idx; nrows_dev = off + B;
-        bucket_idx = idx2; nbuckets_dev = off2 + B;
+        pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1;
         return DIGAT_OK;
+    };
+    auto publish_live_rows = [&]() {
+        rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
     };
     const bool want_live = L > 0 && g_live_rows_on && live_ws;
     SideStream* side = side_stream();
@@ -521,6 +527,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rc = news_project(0, Xn_in, side ? side->s : st);
         if (rc) return rc;
     }
+    const bool live_early = side && want_live && (news_early || group_early);   // the side stream is already forked
+    if (live_early) {
+        rc = find_live_rows(side->s);
+        if (rc) return rc;
+    }
     rc = from_c_n(0, st);
     if (rc) return rc;
     rc = user_ctx_tail(Xu[0], nullptr);            // c_u (:192)
@@ -569,8 +580,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
         if (i == 0 && want_live) {
-            rc = find_live_rows(sn);
-            if (rc) return rc;
+            if (!live_early) {
+                rc = find_live_rows(sn);
+                if (rc) return rc;
+            }
+            publish_live_rows();                   // consumers: the user context after this layer's join, layers >= 1
         }
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
         if (rc) return rc;
