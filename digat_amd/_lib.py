@@ -70,6 +70,9 @@ _SIGNATURES = {
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
     "digat_gat_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_gat_fwd": (C.c_int, [_f] * 7 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_sag_cos_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
+    "digat_sag_cos_topk": (C.c_int, [_f, _f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, _f, _f, _f, C.c_size_t, _f]),
+    "digat_sag_news_graph": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float] + [_f] * 5),
     "digat_msa_split_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_split_msa_weights": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f, _f]),
     "digat_msa_workspace_bytes": (C.c_size_t, [C.c_int] * 6),

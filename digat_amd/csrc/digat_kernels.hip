@@ -862,3 +862,4 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 #include "digat_eval.inc"
 #include "digat_news.inc"
 #include "digat_gat.inc"
+#include "digat_sag.inc"

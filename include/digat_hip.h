@@ -265,6 +265,25 @@ size_t digat_gat_workspace_bytes(int B, int n, int d);
 int digat_gat_fwd(const float* X, const uint8_t* A, const float* W, const float* bW, const float* a1, const float* a2,
                   float* out, int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- semantic-augmented-graph construction: construct_SAG.py ------------------------------------
+ * generate_cos_similarities (construct_SAG.py:112-162), one category: title/content [n, dim], corpus_title/corpus_content
+ * [m, dim] fp32 sentence embeddings; k = min(top_M, m - 1) + 1 <= 32, dim % 16 == 0.  values / indices [5, n, k]
+ * (fp32 / int32), kinds in the reference's return order: title-title, content-content, title-content (title query vs
+ * corpus contents), content-title, and the mean of the four; every row sorted descending as torch.topk returns it
+ * (equal values: lower corpus index first). */
+size_t digat_sag_cos_topk_workspace_bytes(int64_t n, int64_t m, int dim);
+int digat_sag_cos_topk(const float* title, const float* content, int64_t n, const float* corpus_title, const float* corpus_content,
+                       int64_t m, int dim, int k, float* values, int32_t* indices, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* generate_news_graph (construct_SAG.py:449-485): sim_index / sim_cos [news_num, top_M] = every news's similar-news list
+ * (news indices, cosines; sim_len [news_num] entries are valid), hop, news_node_num <= 256, threshold = the reference's
+ * similarity_threshold (0.5, :10).  Outputs (all rewritten): news_node_ID [news_num, nn] int32, news_graph
+ * [news_num, nn, nn] bytes, news_graph_mask [news_num, nn] bytes.  *overflow (device int32) is set to 1 when a walk needs
+ * more than news_node_num nodes (the reference raises IndexError there). */
+int digat_sag_news_graph(const int32_t* sim_index, const float* sim_cos, const int32_t* sim_len, int64_t news_num, int top_M, int hop,
+                         int news_node_num, float threshold, int32_t* news_node_ID, uint8_t* news_graph, uint8_t* news_graph_mask,
+                         int32_t* overflow, void* stream);
+
 /* ---- news encoder (upstream of the path): newsEncoders.MSA.forward in eval mode ------------------
  * newsEncoders.py:70-82 with layers.MultiHeadAttention (layers.py:50-88) and layers.Attention (:91-115).
  * title_text [T, Lw] int32 token ids (rows of word_embedding), title_mask [T, Lw] bytes (0 = padding: masked only in

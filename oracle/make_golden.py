@@ -345,6 +345,60 @@ def fixture_msa():
              input_checksum=checksum({"t": text, "m": mask}, state), out_news_representation=out.numpy(), **extra)
 
 
+def fixture_sag():
+    """SAG construction.  generate_news_graph (construct_SAG.py:449-485) is the reference function run
+    unchanged on synthetic similarity dictionaries.  generate_cos_similarities (:112-162) moves its tensors with
+    ``.cuda()`` / ``device='cuda'`` (no GPU in this container), so it is run with the module's ``torch`` global replaced
+    by a proxy that drops the device (the same ATen CPU ops in the same order), writing its pickle cache under a scratch
+    directory inside the repository that is removed afterwards."""
+    import shutil
+    import construct_SAG as ref   # the reference's module (sentence_transformers stubbed above)
+    for tag, (news_num, top_M, hop, seed) in {"sag_graph_default": (300, 5, 2, 61), "sag_graph_small": (200, 3, 2, 62),
+                                               "sag_graph_hop1": (120, 3, 1, 63), "sag_graph_hop3": (150, 4, 3, 64)}.items():
+        rng = np.random.default_rng(seed)
+        ids, cos, length = synthetic.make_similarity_lists(rng, news_num, top_M, isolated_frac=0.05)
+        length[rng.random(news_num) < 0.2] = max(1, top_M - 2)                 # lists shorter than top_M
+        length[0] = 0
+        nn = synthetic.news_graph_size(top_M, hop)
+        sim, news_ID_dict = synthetic.similarity_dict(ids, cos, length)
+        node_ID, graph, mask = ref.generate_news_graph("x", sim, news_ID_dict, top_M, hop, nn)
+        save(f"{tag}.npz", meta=np.array([news_num, top_M, hop, nn]), in_sim_index=ids, in_sim_cos=cos, in_sim_len=length,
+             out_news_node_ID=node_ID, out_news_graph=np.packbits(graph), out_news_graph_mask=mask)
+
+    class _CpuTorch:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def zeros(*a, device=None, **k):
+            return torch.zeros(*a, **k)
+
+        @staticmethod
+        def device(*_):
+            return torch.device("cpu")
+
+    scratch = os.path.join(REPO, ".golden_scratch")
+    real_torch, real_cuda = ref.torch, torch.Tensor.cuda
+    ref.torch = _CpuTorch()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, (n, m, dim, top_M, seed) in {"sag_cos_small": (40, 32, 64, 5, 71), "sag_cos_clamped": (24, 4, 32, 5, 72),
+                                              "sag_cos_mpnet": (20, 16, 768, 5, 73)}.items():
+            shutil.rmtree(scratch, ignore_errors=True)
+            os.makedirs(os.path.join(scratch, "x-SAG", "cos"))
+            title, content = synthetic.make_semantic_embeddings(max(n, m), dim, seed=seed)
+            args = [T(title[:n]), T(content[:n]), T(title[:m]), T(content[:m])]   # the corpus is a subset of the category's news (rows [:n] query, [:m] corpus)
+            res = ref.generate_cos_similarities(os.path.join(scratch, "x"), top_M, "c", *args)
+            names = [f"out_{kind}_{what}" for kind in ("title", "content", "title_content", "content_title", "average")
+                     for what in ("values", "indices")]
+            save(f"{tag}.npz", meta=np.array([n, m, dim, top_M]), in_title_all=title, in_content_all=content,
+                 **{k: v.numpy() for k, v in zip(names, res)})
+    finally:
+        ref.torch = real_torch
+        torch.Tensor.cuda = real_cuda
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -357,6 +411,7 @@ def main():
     fixture_default(ge)
     fixture_ablations(ge)
     fixture_msa()
+    fixture_sag()
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ Timing with torch events on the current stream, median of --iters launches.
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -135,6 +136,36 @@ def bench_msa(T=8192, Lw=32, V=30000, dm=300, h=16, dk=25, att=256):
           f"   stock torch {m2:.2f} ms   max|diff| {float((a - b).abs().max()):.2e}")
 
 
+def bench_sag(n=30000, m=30000, dim=768, top_M=5, news_num=65238, hop=2, cpu_rows=32):
+    """SAG construction: cosine top-k of one category of n news against an m-news corpus, and the walk over
+    news_num similarity lists; the reference's per-news loop (oracle restatement) timed on cpu_rows rows beside it."""
+    import time
+    from digat_amd import construct_SAG, synthetic
+    from oracle import sag_oracle
+    dev = torch.device("cuda:0")
+    title, content = synthetic.make_semantic_embeddings(max(n, m), dim, seed=3, clusters=200)
+    t, c = torch.from_numpy(title).to(dev), torch.from_numpy(content).to(dev)
+    ms, _ = timeit(lambda: construct_SAG.cos_topk_device(t[:n], c[:n], t[:m], c[:m], top_M), iters=3, warm=1)
+    flops = 4 * 2.0 * n * m * dim
+    t0 = time.perf_counter()
+    sag_oracle.generate_cos_similarities(*(torch.from_numpy(x) for x in (title[:cpu_rows], content[:cpu_rows], title[:m], content[:m])), top_M)
+    cpu_ms_row = (time.perf_counter() - t0) * 1e3 / cpu_rows
+    print(f"SAG cosine top-{top_M + 1}: n={n} x m={m} x dim={dim}: HIP {ms:.1f} ms ({n / ms * 1e3:.0f} news/s, {flops / ms / 1e9:.1f} TFLOP/s fp32-eq)"
+          f"   CPU per-news loop {cpu_ms_row:.1f} ms/news ({1e3 / cpu_ms_row:.0f} news/s, {torch.get_num_threads()} threads, {cpu_rows} rows)")
+    rng = np.random.default_rng(4)
+    ids, cos, length = synthetic.make_similarity_lists(rng, news_num, top_M, isolated_frac=0.02)
+    nn = synthetic.news_graph_size(top_M, hop)
+    dv = [torch.from_numpy(a).to(dev) for a in (ids, cos, length)]
+    ms2, _ = timeit(lambda: construct_SAG.news_graph_device(*dv, top_M=top_M, hop=hop, news_node_num=nn), iters=5, warm=1)
+    sub = min(news_num, 4000)
+    sub_ids = np.minimum(ids[:sub], sub - 1)
+    t0 = time.perf_counter()
+    sag_oracle.generate_news_graph(sub_ids, cos[:sub], length[:sub], top_M, hop, nn)
+    cpu2 = (time.perf_counter() - t0) * 1e3 / sub
+    print(f"SAG walk: {news_num} news, top_M={top_M}, hop={hop}, {nn} nodes: HIP {ms2:.2f} ms ({news_num / ms2 / 1e3:.2f} M news/s)"
+          f"   CPU walk {cpu2 * news_num:.0f} ms ({1 / cpu2:.1f} k news/s, 1 thread, {sub} rows)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "xattn"
     nums = [int(v) for v in sys.argv[2:]]
@@ -144,6 +175,8 @@ if __name__ == "__main__":
         bench_xattn(*nums, density="mind")
     elif what == "msa":
         bench_msa(*nums)
+    elif what == "sag":
+        bench_sag(*nums)
     elif what == "topic":
         bench_topic(*nums)
     elif what == "linear":
