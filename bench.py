@@ -126,26 +126,26 @@ def main():
     # The driver's scoring loop (util.score_rows): the grouped inputs of batch k+1 are gathered on a side stream while
     # batch k is scored (util.GroupedBatchPipeline).  The pipeline takes batches in order, so `step` ignores its
     # argument and walks a cursor over the dev rows, cycled.
-    state = {"k": 0, "pipe": None, "base": 0}
+    cursor = {"k": 0, "pipe": None, "base": 0}
     CHUNK = 512                                    # batches per pipeline instance (index arrays are built per instance)
 
     def step(_i):
-        k = state["k"]
-        if state["pipe"] is None or k - state["base"] >= CHUNK:
-            state["base"] = k
+        k = cursor["k"]
+        if cursor["pipe"] is None or k - cursor["base"] >= CHUNK:
+            cursor["base"] = k
             order = [(((k + j) % nbatches) * B, min(((k + j) % nbatches) * B + B, dc.rows)) for j in range(CHUNK)]
-            state["order"] = order
-            state["pipe"] = None if args.per_row_users else util.GroupedBatchPipeline(dc, order, imp_host)
-        s, e = state["order"][k - state["base"]]
+            cursor["order"] = order
+            cursor["pipe"] = None if args.per_row_users else util.GroupedBatchPipeline(dc, order, imp_host)
+        s, e = cursor["order"][k - cursor["base"]]
         with torch.no_grad():
-            inputs = state["pipe"].take(k - state["base"]) if state["pipe"] is not None else None
+            inputs = cursor["pipe"].take(k - cursor["base"]) if cursor["pipe"] is not None else None
             if inputs is None:
                 scores_buf[:e - s] = model.inference(*util.gather_batch(dc, s, e))
             else:
                 scores_buf[:e - s] = model.inference_grouped(*inputs)
-            if state["pipe"] is not None:
-                state["pipe"].scored(k - state["base"])
-        state["k"] = k + 1
+            if cursor["pipe"] is not None:
+                cursor["pipe"].scored(k - cursor["base"])
+        cursor["k"] = k + 1
         return e - s
 
     def fence():

@@ -407,16 +407,16 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         return launch_gemm(g, sq);
     };
-    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend) -> int {
-        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, st);
+    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq) -> int {
+        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
         g.wsplit = (const unsigned short*)p->featureAffine_wsplit;       // non-NULL: bf16x6
         if (bucket_idx && gemm_is_bf16x6(g)) { g.rowidx = bucket_idx; g.nrows_dev = nbuckets_dev; }   // unmasked buckets only
-        e = launch_gemm(g, st);
+        e = launch_gemm(g, sq);
         if (e) return e;
-        return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, st);
+        return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, sq);
     };
     auto news_ctx = [&](const float* Xn_cur, hipStream_t sq) -> int {
         const long ldx = (long)N * d;
@@ -534,7 +534,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     }
     rc = from_c_n(0, st);
     if (rc) return rc;
-    rc = user_ctx_tail(Xu[0], nullptr);            // c_u (:192)
+    rc = user_ctx_tail(Xu[0], nullptr, st);        // c_u (:192)
     if (rc) return rc;
     const float* xn_cur = Xn_in;
     int un = 0, nn = 0;
@@ -543,9 +543,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         const digat_layer_params& lu = p->user[i];
         const float* r_user = r_user2[i & 1];     // K3 of the user graph, from the previous c_n
         hipStream_t sn = side ? side->s : st;
-        if (side) {
+        if (side && i == 0) {                      // the news chain starts from the initial c_u (caller's stream)
             if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(sn, side->fork, 0) != hipSuccess)
                 return DIGAT_ERR_LAUNCH;
+        }
+        if (side && i > 0) {                       // K3 of this layer's user graph + the live lists come from the side stream
+            if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
         }
         // ---- user graph, Eq. 8 (caller's stream)
         if (i == 0 && row_group) {
@@ -578,6 +581,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr);
         }
         if (rc) return rc;
+        if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
         if (i == 0 && want_live) {
             if (!live_early) {
@@ -603,16 +607,20 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         rc = from_c_n(i + 1, sn);                  // queries (+ next K3, into the other r_user buffer) from the UPDATED c_n
         if (rc) return rc;
-        if (side) {
-            if (hipEventRecord(side->join, sn) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
-                return DIGAT_ERR_LAUNCH;
-        }
-        if (news_early && i + 1 < L) {             // the next layer's news projections need only Xn: under the user context
+        if (side && hipEventRecord(side->join, sn) != hipSuccess) return DIGAT_ERR_LAUNCH;      // the next user-graph update may start
+        if (news_early && i + 1 < L) {             // the next layer's news projections need only Xn
             rc = news_project(i + 1, xn_cur, sn);
             if (rc) return rc;
         }
-        rc = user_ctx_tail(Xu[un], c_u);           // c_u += ... (:197)
+        // The user context of this layer feeds the next NEWS update and the result, not the next user-graph update: it runs
+        // on the side stream once the caller's stream has written the user nodes, under the next layer's projection GEMM.
+        if (side && hipStreamWaitEvent(sn, side->fork, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
+        rc = user_ctx_tail(Xu[un], c_u, sn);       // c_u += ... (:197)
         if (rc) return rc;
+    }
+    if (side && L > 0) {
+        if (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
+            return DIGAT_ERR_LAUNCH;
     }
     return DIGAT_OK;
 }

@@ -1,0 +1,48 @@
+"""GPU suite: bench.py end to end, as the driver launches it (one process; two ranks under torch.distributed.run with
+both ranks on the box's single GPU and gloo for the control-plane scalars)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"}
+
+
+def _last_json_line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_prints_the_contract_line():
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "256", "--news", "2048",
+           "--cpu-rows", "256", "--cpu-seconds", "5"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    assert REQUIRED <= set(line) and "cpu_baseline" in line
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["warmup"] == 2 and line["value"] > 0
+    assert line["unit"] == "impressions/s" and line["dtype"] == "f32" and line["vs_baseline"] is None
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and 0 < roof["frac"] < 1
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert line["auc_match"]["max_abs_metric_diff"] <= line["auc_match"]["tolerance"]
+
+
+def test_bench_two_ranks_sum_their_rows():
+    env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "256", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None       # rank 0 at N=1 only
