@@ -32,7 +32,7 @@ class MsaParams(C.Structure):
 
 
 class Params(C.Structure):
-    _fields_ = ([("d", C.c_int32), ("depth", C.c_int32), ("category_num", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = ([("d", C.c_int32), ("depth", C.c_int32), ("category_num", C.c_int32), ("flags", C.c_int32)]
                 + [(k, _f) for k in ("topic_node_embedding", "cand_K", "cand_Q", "cand_bQ",
                                      "news_graph_W", "news_graph_b", "user_news_K", "user_news_Q",
                                      "user_news_bQ", "featureAffine_W", "featureAffine_b",

@@ -156,7 +156,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
-                      const uint8_t* live = nullptr) {
+                      const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -174,8 +174,16 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
+    const int* skip_if = nullptr;
+    if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
+        const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
+                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4};
+        const int rcs = launch_sparse(sg, st);
+        if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
+        skip_if = sparse_flag;
+    }
     return launch_xattn_pairwise(P, Q, h, X, a, A, out, alpha, B, n, d, st, listed ? live : nullptr, nullptr, nullptr,
-                                 alpha_out != nullptr);
+                                 alpha_out != nullptr, skip_if);
 }
 
 int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
@@ -366,6 +374,7 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // caller's stream.
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
+static int g_sparse_per_node = getenv("DIGAT_SPARSE_PER_NODE") ? atoi(getenv("DIGAT_SPARSE_PER_NODE")) : 12;
 static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
 static SideStream* side_stream() {
     static SideStream tab[16];
@@ -431,6 +440,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         return launch_gemm(g, sq);
     };
 
+    const bool want_live = L > 0 && g_live_rows_on && live_ws;
+    // Eq. 8 of the user graph: the sparse kernel, the dense pair, or both with the device choosing (p->flags; the choice
+    // comes out of the adjacency pass of find_live_rows)
+    int sparse_mode = p->flags & 3;
+    if (sparse_mode == 3 || (sparse_mode == DIGAT_XATTN_AUTO && !(L > 0 && live_ws))) sparse_mode = DIGAT_XATTN_DENSE;
+    const int* sparse_flag = nullptr;
+    const bool want_scan = want_live || sparse_mode == DIGAT_XATTN_AUTO;      // the adjacency pass: live lists and / or the decision
     // live rows of the user graph for the projections of layers >= 1 (DIGAT_NO_SKIP=1: every row)
     const int* rowidx = nullptr;
     const int* nrows_dev = nullptr;
@@ -446,12 +462,19 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         int* cnt2 = idx + align_up((size_t)B * U, 64);
         int* off2 = cnt2 + align_up((size_t)B, 64);
         int* idx2 = off2 + align_up((size_t)B + 1, 64);
-        uint8_t* flags1 = (uint8_t*)(idx2 + align_up((size_t)B * C1, 64));
+        int* entries = idx2 + align_up((size_t)B * C1, 64);
+        int* flag = entries + align_up((size_t)B, 64);
+        uint8_t* flags1 = (uint8_t*)(flag + 64);
         uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           flags1, cnt);
+                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr);
         DIGAT_CHECK_LAUNCH();
+        if (sparse_mode == DIGAT_XATTN_AUTO) {
+            hipLaunchKernelGGL(sparse_decide_kernel, dim3(1), dim3(1024), 0, sq, (const int*)entries, B, U, g_sparse_per_node, flag);
+            DIGAT_CHECK_LAUNCH();
+            sparse_flag = flag;
+        }
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt, off, B);
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags1, (const int*)off, B, U, idx);
@@ -468,7 +491,6 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     auto publish_live_rows = [&]() {
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
     };
-    const bool want_live = L > 0 && g_live_rows_on && live_ws;
     SideStream* side = side_stream();
     // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
     // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
@@ -493,9 +515,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         const digat_layer_params& lu = p->user[0];
         const size_t ndg = (size_t)G * U * d;
         const size_t nd = (size_t)B * U * d;
-        float* Xg = Xu[1];                                  // group nodes and P of the groups: free until layer 0's
-        float* P0 = Xg + ndg;                               // output is written (2 ndg <= nd)
+        float* Xg = Xu[1];                                  // group nodes: free until layer 0's output is written
         float* h0 = (float*)xws;
+        float* P0 = h0 + ndg;                               // behind the groups' h in the h slot (2 ndg <= nd)
         float* Q0 = h0 + 2 * nd;
         const long total4 = (long)ndg / 4;
         int blocks = (int)((total4 + 255) / 256);
@@ -514,22 +536,24 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     // Work that depends on the inputs alone goes out on the side stream at once, under the initial user context:
     // the group projections of layer 0 and (small news graphs) the news projections of layer 0.
     const bool group_early = side && L > 0 && row_group;
-    if (side && (news_early || group_early)) {
+    const bool live_early = side && want_scan;
+    if (side && (news_early || group_early || live_early)) {
         if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
             return DIGAT_ERR_LAUNCH;
+    }
+    if (live_early) {                  // first: layer 0 may need the sparse / dense decision
+        rc = find_live_rows(side->s);
+        if (rc) return rc;
     }
     if (group_early) {
         rc = group_project(side->s);
         if (rc) return rc;
+    }
+    if (group_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO)) {
         if (hipEventRecord(side->early, side->s) != hipSuccess) return DIGAT_ERR_LAUNCH;
     }
     if (news_early) {
         rc = news_project(0, Xn_in, side ? side->s : st);
-        if (rc) return rc;
-    }
-    const bool live_early = side && want_live && (news_early || group_early);   // the side stream is already forked
-    if (live_early) {
-        rc = find_live_rows(side->s);
         if (rc) return rc;
     }
     rc = from_c_n(0, st);
@@ -551,45 +575,56 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
         }
         // ---- user graph, Eq. 8 (caller's stream)
+        if (i == 0 && want_scan && !live_early) {              // no side stream: the lists and the sparse / dense decision first
+            rc = find_live_rows(st);
+            if (rc) return rc;
+        }
+        if (i == 0 && side && (group_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO))) {
+            if (hipStreamWaitEvent(st, side->early, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
+        }
         if (i == 0 && row_group) {
             const size_t ndg = (size_t)G * U * d;
             const size_t nd = (size_t)B * U * d;
-            float* P0 = Xu[1] + ndg;
             float* h0 = (float*)xws;
+            float* P0 = h0 + ndg;
             float* P = h0 + nd;
             float* Q0 = P + nd;
-            if (group_early) {
-                if (hipStreamWaitEvent(st, side->early, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
-            } else {
+            if (!group_early) {
                 rc = group_project(st);
                 if (rc) return rc;
             }
-            float* alpha = (float*)((char*)xws + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
-            {
-                const long total4 = (long)nd / 4;
-                int blocks = (int)((total4 + 255) / 256);
-                if (blocks > 4096) blocks = 4096;
-                ProfScope prof(DIGAT_KERNEL_GLUE, (double)nd * 4, st);
-                hipLaunchKernelGGL(expand_proj_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)P0, (const float4*)r_user,
-                                   row_group, (float4*)P, (long)B, U, d / 4);
-                DIGAT_CHECK_LAUNCH();
+            rc = DIGAT_OK;
+            if (sparse_mode != DIGAT_XATTN_DENSE && d / 4 <= 256) {
+                // P' = K1 (the groups' P0) + K3 (this layer's r_user) is formed inside the kernel: nothing is expanded
+                const SparseArgs sg{P0, Q0, h0, Xu[0], lu.a, Au, Xu[1], r_user, row_group, nullptr,
+                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4};
+                rc = launch_sparse(sg, st);
             }
-            rc = launch_xattn_pairwise(P, Q0, h0, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st, nullptr, row_group);
+            if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
+                const int* skip_if = sparse_mode == DIGAT_XATTN_AUTO && d / 4 <= 256 ? sparse_flag : nullptr;
+                float* alpha = (float*)((char*)xws + align_up(3 * nd * 4, 256) + align_up((size_t)B * d * 4, 256));
+                {
+                    const long total4 = (long)nd / 4;
+                    int blocks = (int)((total4 + 255) / 256);
+                    if (blocks > 4096) blocks = 4096;
+                    ProfScope prof(DIGAT_KERNEL_GLUE, skip_if ? 0.0 : (double)nd * 4, st);
+                    hipLaunchKernelGGL(expand_proj_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)P0, (const float4*)r_user,
+                                       row_group, (float4*)P, (long)B, U, d / 4, skip_if);
+                    DIGAT_CHECK_LAUNCH();
+                }
+                rc = launch_xattn_pairwise(P, Q0, h0, Xu[0], lu.a, Au, Xu[1], alpha, B, U, d, st, nullptr, row_group, nullptr, true,
+                                           skip_if);
+            }
         } else {
             // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
-                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr);
+                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr, sparse_mode,
+                            sparse_flag);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
-        if (i == 0 && want_live) {
-            if (!live_early) {
-                rc = find_live_rows(sn);
-                if (rc) return rc;
-            }
-            publish_live_rows();                   // consumers: the user context after this layer's join, layers >= 1
-        }
+        if (i == 0 && want_live) publish_live_rows();       // consumers: the user context of this layer, layers >= 1
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
         if (rc) return rc;
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
@@ -637,8 +672,9 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += 5 * align_up((size_t)B * d * 4, 256);         // folded path: kq_topic, kq_user, r_user x2, r_news
     tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
     // live-node and live-bucket counts, offsets, lists (int) and flags (bytes)
-    tot += (2 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
-            + align_up((size_t)B * (C + 1), 64)) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256);
+    // + adjacency entries per row and the sparse / dense decision (int)
+    tot += (3 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
+            + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256);
     return tot;
 }
 

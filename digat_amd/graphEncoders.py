@@ -75,6 +75,9 @@ class DIGAT(GraphEncoder):
         # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default),
         # "fp32" = v_mfma_f32_16x16x4_f32
         self.projection_mode = "bf16x6"
+        # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
+        # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
+        self.user_xattn_mode = "auto"
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -114,6 +117,7 @@ class DIGAT(GraphEncoder):
                                          "(call model.cuda()); there is no CPU path")
         P = _lib.Params()
         P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
+        P.flags = {"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode]
         P.topic_node_embedding = self.topic_node_embedding.data_ptr()
         P.cand_K = self.candidate_attention.K.weight.data_ptr()
         P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
@@ -174,7 +178,7 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.projection_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.projection_mode, self.user_xattn_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))

@@ -108,6 +108,13 @@ int digat_topic_pool_fwd(const float* Xu, const float* kq, const int64_t* cat_id
 
 /* ---- a5: DIGAT.forward / DIGAT.inference  (graphEncoders.py:177-198) ---------------------------
  * Parameter block: the reference's state_dict tensors by name (prefix graph_encoder. in Model). */
+/* Eq. 8 of the USER graph inside the encoder entry points (digat_params.flags, bits 0-1).  MIND user graphs hold ~4 entries
+ * per adjacency row; xattn_sparse_kernel visits only those (score, softmax and aggregation in one launch), the dense pair
+ * (tile score kernel + MFMA aggregation) streams whole rows.  AUTO: both are launched and a device-side count of the
+ * adjacency entries (<= 12 per node on average: sparse) lets one of them return at its first instruction — no host
+ * synchronisation; results differ between the two only by fp32 summation order.  Callers that know their graphs choose. */
+enum { DIGAT_XATTN_AUTO = 0, DIGAT_XATTN_DENSE = 1, DIGAT_XATTN_SPARSE = 2 };
+
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */
     const float *F1;          /* {g}_graph_attention_ffn1.i.weight        */
@@ -125,7 +132,7 @@ typedef struct digat_params {
     int32_t d;                /* news_embedding_dim                        */
     int32_t depth;            /* graph_depth                               */
     int32_t category_num;     /* C (topic_node_embedding rows)             */
-    int32_t reserved;
+    int32_t flags;            /* bits 0-1: Eq. 8 of the user graph, DIGAT_XATTN_AUTO / _DENSE / _SPARSE (see below); other bits 0 */
     const float *topic_node_embedding;                      /* [C,d]        */
     const float *cand_K, *cand_Q, *cand_bQ;                 /* candidate_attention */
     const float *news_graph_W, *news_graph_b;               /* [d,2d], [d]  */

@@ -427,7 +427,8 @@ def test_encoder_call_is_graph_capturable():
     assert torch.equal(captured[0], eager[0]) and torch.equal(captured[1], eager[1])
 
 
-def test_edge_cases_at_production_shapes_with_row_lists_active():
+@pytest.mark.parametrize("mode", ["auto", "dense", "sparse"])
+def test_edge_cases_at_production_shapes_with_row_lists_active(mode):
     """E1-E5 at d=400, U=67 and a batch large enough that the row lists (live nodes, live buckets) are
     in use: empty histories, isolated candidates, single-category histories, adjacency rows without any edge (not
     even the self loop, graph no longer symmetric).  HIP (per-row and grouped) vs the oracle."""
@@ -458,6 +459,7 @@ def test_edge_cases_at_production_shapes_with_row_lists_active():
                                              tb["user_news_embedding"], tb["user_graph"], tb["user_category_mask"],
                                              tb["user_category_indices"], c_n0)
     enc = make_encoder(state, N, H, C, d, L)
+    enc.user_xattn_mode = mode                                     # the sparse kernel, the dense pair, or the device's choice
     db = to_dev(per_row)
     du = to_dev({k: users[k] for k in ukeys})
     with torch.no_grad():
@@ -472,3 +474,43 @@ def test_edge_cases_at_production_shapes_with_row_lists_active():
     close(got_n, want_n, "edges@400: news ctx", rtol=2e-5, atol=2e-5)
     close(got_u, want_u, "edges@400: user ctx", rtol=2e-5, atol=2e-5)
     assert torch.equal(grp_n, got_n) and torch.equal(grp_u, got_u)
+
+
+@pytest.mark.parametrize("density", ["mind", "dense"])
+def test_user_graph_eq8_modes_agree_and_auto_picks_by_density(density):
+    """Eq. 8 of the user graph: the sparse edge-list kernel and the dense tile + MFMA pair against the oracle on the same
+    batch, per-row and grouped; "auto" (a device-side count of the adjacency entries) reproduces the sparse kernel's bits on
+    MIND-shaped user graphs and the dense pair's on fully connected ones."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 192, 10, 50, 17, 400, 2
+    G = B // 4
+    state = synthetic.make_state_dict(d, C, L, seed=51, bias_std=0.05)
+    users = synthetic.make_encoder_batch(G, N, H, C, d, seed=52, empty_history_rows=(3,))
+    if density == "dense":
+        rng = np.random.default_rng(53)
+        users["user_graph"] = (rng.random(users["user_graph"].shape) < 0.6) | np.eye(H + C, dtype=bool)[None]
+    cands = synthetic.make_encoder_batch(B, N, H, C, d, seed=54)
+    row_group = np.repeat(np.arange(G), 4).astype(np.int32)
+    ukeys = ("user_news_embedding", "user_graph", "user_category_mask", "user_category_indices")
+    nkeys = ("news_graph_embeddings", "news_graph", "news_graph_mask")
+    per_row = {k: (users[k][row_group] if k in ukeys else cands[k]) for k in nkeys + ukeys}
+    p = O.as_params(state)
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in per_row.items()}
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, tb["news_graph_embeddings"], tb["news_graph_mask"])
+        want = O.encoder_inference(p, L, *(tb[k] for k in nkeys + ukeys), c_n0)
+    enc = make_encoder(state, N, H, C, d, L)
+    db, du = to_dev(per_row), to_dev({k: users[k] for k in ukeys})
+    rg = torch.from_numpy(row_group).to(_dev())
+    out = {}
+    with torch.no_grad():
+        c0 = enc.compute_news_graph_context(db["news_graph_embeddings"], db["news_graph_mask"])
+        for mode in ("auto", "dense", "sparse"):
+            enc.user_xattn_mode = mode
+            out[mode] = enc.inference(*(db[k] for k in nkeys + ukeys), c0)
+            grouped = enc.inference_grouped(*(db[k] for k in nkeys), *(du[k] for k in ukeys), rg, c0)
+            assert torch.equal(grouped[0], out[mode][0]) and torch.equal(grouped[1], out[mode][1]), mode
+            close(out[mode][0], want[0], f"{density}/{mode}: news ctx", rtol=2e-5, atol=2e-5)
+            close(out[mode][1], want[1], f"{density}/{mode}: user ctx", rtol=2e-5, atol=2e-5)
+    same_as = "sparse" if density == "mind" else "dense"
+    assert torch.equal(out["auto"][0], out[same_as][0]) and torch.equal(out["auto"][1], out[same_as][1])
