@@ -23,6 +23,9 @@ import torch
 from . import evaluate
 
 
+SPARSE_ENTRIES_PER_NODE = 12        # the library's own threshold for DIGAT_XATTN_AUTO (digat_kernels.hip)
+
+
 @dataclass
 class DeviceCorpus:
     """Device-resident corpus tables with the reference's array names (MIND_corpus.py:189-298)."""
@@ -102,6 +105,13 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
             e = min(s + batch_size, news_num)
             c_n0[s:e] = encoder.compute_news_graph_context(dc.SA_news_representations[s:e], dc.news_graph_mask[s:e])
     dc.c_n0 = c_n0
+    # Eq. 8 of the user graph: the corpus is known here, so the sparse / dense choice the library would otherwise make on
+    # the device per batch (both variants launched, one returning at once) is made once, on the host, from the mean
+    # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" is left alone.
+    if getattr(encoder, "user_xattn_mode", None) == "auto" and dc.user_graph.numel() > 0:
+        U = dc.user_graph.shape[1]
+        per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
+        encoder.user_xattn_mode = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
