@@ -177,7 +177,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     const int* skip_if = nullptr;
     if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
         const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
-                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4};
+                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4,
+                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr};
         const int rcs = launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
         skip_if = sparse_flag;
@@ -597,7 +598,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             if (sparse_mode != DIGAT_XATTN_DENSE && d / 4 <= 256) {
                 // P' = K1 (the groups' P0) + K3 (this layer's r_user) is formed inside the kernel: nothing is expanded
                 const SparseArgs sg{P0, Q0, h0, Xu[0], lu.a, Au, Xu[1], r_user, row_group, nullptr,
-                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4};
+                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, nullptr, nullptr};
                 rc = launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
