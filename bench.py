@@ -120,7 +120,6 @@ def main():
     nbatches = max(1, dc.rows // B)
     mean_cand = corpus.rows / float(spec.impressions)
 
-    scores_buf = torch.empty(B, dtype=torch.float32, device=dev)
     imp_host = corpus.row_impression
 
     # The driver's scoring loop (util.score_rows): the grouped inputs of batch k+1 are gathered on a side stream while
@@ -129,6 +128,12 @@ def main():
     cursor = {"k": 0, "pipe": None, "base": 0}
     CHUNK = 512                                    # batches per pipeline instance (index arrays are built per instance)
 
+    # consecutive batches alternate over two HIP streams, as util.score_rows does (util.batch_streams): batch k+1's
+    # opening kernels run under batch k's last layer.  cursor["lanes"] = 1 puts every batch on the current stream.
+    lanes = util.batch_streams(dev, 2)
+    lane_scores = [torch.empty(B, dtype=torch.float32, device=dev) for _ in lanes]
+    cursor["lanes"] = len(lanes)
+
     def step(_i):
         k = cursor["k"]
         if cursor["pipe"] is None or k - cursor["base"] >= CHUNK:
@@ -136,13 +141,16 @@ def main():
             order = [(((k + j) % nbatches) * B, min(((k + j) % nbatches) * B + B, dc.rows)) for j in range(CHUNK)]
             cursor["order"] = order
             cursor["pipe"] = None if args.per_row_users else util.GroupedBatchPipeline(dc, order, imp_host)
+            for extra in lanes[1:]:
+                extra.wait_stream(lanes[0])
         s, e = cursor["order"][k - cursor["base"]]
-        with torch.no_grad():
+        lane = k % cursor["lanes"]
+        with torch.no_grad(), torch.cuda.stream(lanes[lane]):
             inputs = cursor["pipe"].take(k - cursor["base"]) if cursor["pipe"] is not None else None
             if inputs is None:
-                scores_buf[:e - s] = model.inference(*util.gather_batch(dc, s, e))
+                lane_scores[lane][:e - s] = model.inference(*util.gather_batch(dc, s, e))
             else:
-                scores_buf[:e - s] = model.inference_grouped(*inputs)
+                lane_scores[lane][:e - s] = model.inference_grouped(*inputs)
             if cursor["pipe"] is not None:
                 cursor["pipe"].scored(k - cursor["base"])
         cursor["k"] = k + 1
@@ -189,12 +197,14 @@ def main():
     # durations above include the sharing.  A second, untimed pass on one stream gives each kernel's duration
     # with the chip to itself (reported as roofline.isolated_*; `frac` stays the timed region's).
     prev = _lib.lib().digat_set_side_stream(0)
+    cursor["lanes"] = 1                          # ... and every batch on the same caller stream
     _lib.profile_start(64 * (args.steps + 1) * (L + 1))
     for i in range(min(args.steps, 10)):
         step(args.warmup + i)
     torch.cuda.synchronize()
     prof_iso = _lib.profile_stop()
     _lib.lib().digat_set_side_stream(prev)
+    cursor["lanes"] = len(lanes)
 
     if world > 1:
         import torch.distributed as dist

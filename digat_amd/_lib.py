@@ -186,9 +186,10 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
-    """A cached scratch buffer per (device, tag), grown on demand.  Kernels launched on one stream
-    run in order, so reusing it across calls is safe."""
-    key = (device, tag)
+    """A cached scratch buffer per (device, stream, tag), grown on demand.  Kernels launched on one stream
+    run in order, so reusing it across calls is safe; calls on different streams (util.score_rows alternates two so
+    that one batch's prologue runs under the previous batch's last layer) get different buffers."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -242,25 +242,46 @@ class GroupedBatchPipeline:
         self._gather(k + 1)
 
 
-def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True) -> torch.Tensor:
+_batch_streams = {}
+
+
+def batch_streams(device, count: int = 2):
+    """[current stream, extra streams ...] for scoring consecutive batches on alternating streams: a batch begins with
+    small input-only kernels (user-node build, liveness, layer-0 projections of the groups) and ends with the last
+    user context on the library's side stream — on one stream the GPU idles through both; with two, batch k+1's opening
+    runs under batch k's last layer.  Every stream has its own scratch (``_lib.workspace`` is keyed by stream)."""
+    cur = torch.cuda.current_stream(device)
+    extra = _batch_streams.setdefault((device, cur.cuda_stream), [])
+    while len(extra) < count - 1:
+        extra.append(torch.cuda.Stream(device=device))
+    return [cur] + extra[:count - 1]
+
+
+def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True,
+               streams: int = 2) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
-    tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``."""
-    scores = torch.empty(end - start, dtype=torch.float32, device=dc.news_embedding.device)
+    tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``.  ``streams``:
+    consecutive batches alternate over this many HIP streams (same kernels, same bits: see ``batch_streams``)."""
+    dev = dc.news_embedding.device
+    scores = torch.empty(end - start, dtype=torch.float32, device=dev)
     grouped = grouped and hasattr(model, "inference_grouped")
     batches = [(s, min(s + batch_size, end)) for s in range(start, end, batch_size)]
+    lanes = batch_streams(dev, max(1, streams))
     with torch.no_grad():
-        if grouped and batches:
-            pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy())
-            for k, (s, e) in enumerate(batches):
-                inputs = pipe.take(k)
+        pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy()) if grouped and batches else None
+        for extra in lanes[1:]:
+            extra.wait_stream(lanes[0])                       # the corpus tables, `scores`, the pipeline's index arrays
+        for k, (s, e) in enumerate(batches):
+            with torch.cuda.stream(lanes[k % len(lanes)]):
+                inputs = pipe.take(k) if pipe is not None else None
                 if inputs is not None:
                     scores[s - start:e - start] = model.inference_grouped(*inputs)
                 else:
                     scores[s - start:e - start] = model.inference(*gather_batch(dc, s, e))
-                pipe.scored(k)
-        else:
-            for s, e in batches:
-                scores[s - start:e - start] = model.inference(*gather_batch(dc, s, e))
+                if pipe is not None:
+                    pipe.scored(k)
+    for extra in lanes[1:]:
+        lanes[0].wait_stream(extra)
     return scores
 
 
