@@ -51,10 +51,10 @@ struct ProfScope {
         if (g_prof.enabled && g_prof.used < g_prof.cap) {
             slot = g_prof.used++;
             g_prof.kind[slot] = kind; g_prof.work[slot] = work;
-            hipEventRecord(g_prof.ev[2 * slot], st);
+            (void)hipEventRecord(g_prof.ev[2 * slot], st);
         }
     }
-    ~ProfScope() { if (slot >= 0) hipEventRecord(g_prof.ev[2 * slot + 1], st); }
+    ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st); }
 };
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -883,10 +883,10 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
             if (g_prof.rows_nominal[DIGAT_KERNEL_PROJ] > 0)
                 g_prof_last_live_fraction = (double)rows[DIGAT_KERNEL_PROJ] / g_prof.rows_nominal[DIGAT_KERNEL_PROJ];
         }
-        hipFree(g_prof.rows_dev);
+        (void)hipFree(g_prof.rows_dev);
         g_prof.rows_dev = nullptr;
     }
-    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     free(g_prof.ev); free(g_prof.kind); free(g_prof.work);
     g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.cap = g_prof.used = 0;
     return rc;
