@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
     ap.add_argument("--per-row-users", action="store_true",
                     help="expand the user tensors per row as the reference's driver does (default: once per impression)")
-    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "fp32"],
+    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA")
     return ap.parse_args()
 
@@ -232,7 +232,7 @@ def main():
 
     # HBM traffic of the roofline kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass); their per-launch means are kept under profiles/ and quoted here.
-    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(model.graph_encoder, "projection_mode", "") == "bf16x6"
+    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(model.graph_encoder, "projection_mode", "").startswith("bf16x6")
                else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_sparse_kernel" if getattr(model.graph_encoder, "user_xattn_mode", "") == "sparse" else "xattn_score_kernel",
                "agg": "xattn_agg_kernel",
                "topic": "topic_pool_kernel", "pool": "attn_pool_kernel"}
@@ -265,14 +265,19 @@ def main():
     def roof_of(kind, v):
         per_launch_ms = v["ms"] / v["launches"]
         rate = v["work"] / (v["ms"] * 1e-3)
-        if kind == "proj" and getattr(model.graph_encoder, "projection_mode", "fp32") == "bf16x6":
-            # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split):
-            # price the EXECUTED bf16 flops against the dense bf16 peak, and quote the fp32-equivalent rate
-            return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": 6 * rate / 1e12,
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 6 * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                    "traffic": pmc_traffic(kind), "mfma_dtype": "bf16 (3-way split of f32, 6 products, f32 accumulate)",
+        pmode = getattr(model.graph_encoder, "projection_mode", "fp32")
+        if kind == "proj" and pmode.startswith("bf16x6"):
+            # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split; "bf16x6-pq3": 6 for h,
+            # 3 for P and Q = 4 on average): price the EXECUTED bf16 flops against the dense bf16 peak, and quote the
+            # fp32-equivalent rate
+            nprod = 6 if pmode == "bf16x6" else 4
+            return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": nprod * rate / 1e12,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": nprod * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": pmc_traffic(kind),
+                    "mfma_dtype": "bf16 (3-way split of f32, f32 accumulate; products per fp32 product: %s)"
+                                  % ("6" if nprod == 6 else "6 for h, 3 for P and Q"),
                     "fp32_equivalent_tflops": rate / 1e12, "algorithmic_flops_per_launch": v["work"] / v["launches"],
-                    "executed_flops_per_launch": 6 * v["work"] / v["launches"],
+                    "executed_flops_per_launch": nprod * v["work"] / v["launches"],
                     "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
         if kind in ("proj", "linear"):
             return {"kernel": kind, "bound": "mfma", "achieved": rate / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,

@@ -156,7 +156,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
-                      const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr) {
+                      const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
+                      int pq_x3 = 0) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -170,6 +171,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.nsegs = 3;
     g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
     g.radd = r_given; g.radd_seg = 1; g.rows_per_b = n; // P' = K3 + K1: the reference's left-to-right order
+    g.x3_segs = pq_x3 ? 6 : 0;                          // DIGAT_PROJ_PQ_X3: P and Q (segments 1, 2) with three products
     const bool listed = rowidx && gemm_is_bf16x6(g);
     if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
@@ -447,6 +449,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     int sparse_mode = p->flags & 3;
     if (sparse_mode == 3 || (sparse_mode == DIGAT_XATTN_AUTO && !(L > 0 && live_ws))) sparse_mode = DIGAT_XATTN_DENSE;
     const int* sparse_flag = nullptr;
+    const int pq_x3 = (p->flags & DIGAT_PROJ_PQ_X3) ? 1 : 0;
     const bool want_scan = want_live || sparse_mode == DIGAT_XATTN_AUTO;      // the adjacency pass: live lists and / or the decision
     // live rows of the user graph for the projections of layers >= 1 (DIGAT_NO_SKIP=1: every row)
     const int* rowidx = nullptr;
@@ -505,6 +508,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gp.w[1] = ln.F1; gp.bias[1] = nullptr; gp.y[1] = hn + ndn;
         gp.w[2] = ln.F2; gp.bias[2] = nullptr; gp.y[2] = hn + 2 * ndn;
         gp.nsegs = 3;
+        gp.x3_segs = pq_x3 ? 6 : 0;
         gp.wsplit = (const unsigned short*)ln.wsplit;
         return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
     };
@@ -530,6 +534,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
         gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = Q0;
         gg.nsegs = 3;
+        gg.x3_segs = pq_x3 ? 6 : 0;
         gg.wsplit = (const unsigned short*)lu.wsplit;
         gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
         return launch_gemm(gg, sq, DIGAT_KERNEL_PROJ);
@@ -620,7 +625,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
                             i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr, sparse_mode,
-                            sparse_flag);
+                            sparse_flag, pq_x3);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
@@ -635,7 +640,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
                                        false);
         } else {
-            rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit);
+            rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit,
+                            nullptr, nullptr, nullptr, DIGAT_XATTN_DENSE, nullptr, pq_x3);
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;

@@ -72,8 +72,8 @@ class DIGAT(GraphEncoder):
             setattr(self, f"{g}_graph_attention_ffn3", nn.ModuleList([nn.Linear(d, d, bias=True) for _ in range(L)]))
             setattr(self, f"{g}_graph_attention_a", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
         self._param_block = None
-        # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default),
-        # "fp32" = v_mfma_f32_16x16x4_f32
+        # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default), "bf16x6-pq3" = the same
+        # for h, three of the six products for P and Q (they only feed the score: DIGAT_PROJ_PQ_X3), "fp32" = v_mfma_f32_16x16x4_f32
         self.projection_mode = "bf16x6"
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
@@ -117,7 +117,7 @@ class DIGAT(GraphEncoder):
                                          "(call model.cuda()); there is no CPU path")
         P = _lib.Params()
         P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
-        P.flags = {"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode]
+        P.flags = {"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode] | (4 if self.projection_mode == "bf16x6-pq3" else 0)
         P.topic_node_embedding = self.topic_node_embedding.data_ptr()
         P.cand_K = self.candidate_attention.K.weight.data_ptr()
         P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
@@ -144,7 +144,7 @@ class DIGAT(GraphEncoder):
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
         # bf16x6 projections: split [W | ffn1 | ffn2] of every layer into three bf16 planes (once per weight version)
         P._splits = []
-        if self.projection_mode == "bf16x6" and self.news_embedding_dim % 80 == 0:
+        if self.projection_mode in ("bf16x6", "bf16x6-pq3") and self.news_embedding_dim % 80 == 0:
             L_ = _lib.lib()
             d = self.news_embedding_dim
             nbytes = L_.digat_split_weights_bytes(3 * d, d)

@@ -114,6 +114,10 @@ int digat_topic_pool_fwd(const float* Xu, const float* kq, const int64_t* cat_id
  * adjacency entries (<= 12 per node on average: sparse) lets one of them return at its first instruction — no host
  * synchronisation; results differ between the two only by fp32 summation order.  Callers that know their graphs choose. */
 enum { DIGAT_XATTN_AUTO = 0, DIGAT_XATTN_DENSE = 1, DIGAT_XATTN_SPARSE = 2 };
+/* digat_params.flags bit 2 (folded inference path, bf16x6 projections only): the P and Q projections of Eq. 8 — which only
+ * feed the attention score — with the three leading bf16 products (hi*hi, mid*hi, hi*mid: relative error ~2^-16) instead
+ * of six (~2^-24); h, which carries the values, keeps six.  A third fewer matrix instructions in the projection GEMM. */
+enum { DIGAT_PROJ_PQ_X3 = 4 };
 
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */
@@ -132,7 +136,7 @@ typedef struct digat_params {
     int32_t d;                /* news_embedding_dim                        */
     int32_t depth;            /* graph_depth                               */
     int32_t category_num;     /* C (topic_node_embedding rows)             */
-    int32_t flags;            /* bits 0-1: Eq. 8 of the user graph, DIGAT_XATTN_AUTO / _DENSE / _SPARSE (see below); other bits 0 */
+    int32_t flags;            /* bits 0-1: Eq. 8 of the user graph, DIGAT_XATTN_AUTO / _DENSE / _SPARSE; bit 2: DIGAT_PROJ_PQ_X3 (see below) */
     const float *topic_node_embedding;                      /* [C,d]        */
     const float *cand_K, *cand_Q, *cand_bQ;                 /* candidate_attention */
     const float *news_graph_W, *news_graph_b;               /* [d,2d], [d]  */

@@ -514,3 +514,29 @@ def test_user_graph_eq8_modes_agree_and_auto_picks_by_density(density):
             close(out[mode][1], want[1], f"{density}/{mode}: user ctx", rtol=2e-5, atol=2e-5)
     same_as = "sparse" if density == "mind" else "dense"
     assert torch.equal(out["auto"][0], out[same_as][0]) and torch.equal(out["auto"][1], out[same_as][1])
+
+
+def test_three_product_pq_mode_stays_inside_the_metric_tolerance():
+    """projection_mode "bf16x6-pq3" (DIGAT_PROJ_PQ_X3): P and Q — which only feed the attention score — with three of the six
+    bf16 products, h with all six.  The contexts move by ~1e-5 of their scale (the default mode: ~5e-7); the row logits stay
+    within 1e-4 relative, the ranking metrics' tolerance."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 256, 10, 50, 17, 400, 3
+    state = synthetic.make_state_dict(d, C, L, seed=11, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=12)
+    with torch.no_grad():
+        wn, wu = O.encoder_forward(O.as_params(state), L, *O.batch_tensors(batch))
+    enc = make_encoder(state, N, H, C, d, L)
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    args = [to_dev(batch)[k] for k in keys]
+    err = {}
+    with torch.no_grad():
+        for mode in ("bf16x6", "bf16x6-pq3"):
+            enc.projection_mode = mode
+            gn, gu = enc(*args)
+            err[mode] = max(float((gn.cpu() - wn).abs().max() / wn.abs().max()), float((gu.cpu() - wu).abs().max() / wu.abs().max()))
+            logit, want = (gn * gu).sum(1).cpu(), (wn * wu).sum(1)
+            assert float(((logit - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-4, mode
+    assert err["bf16x6"] < 2e-6 and err["bf16x6-pq3"] < 5e-5, err
+    assert err["bf16x6-pq3"] > err["bf16x6"]            # the mode is really on
