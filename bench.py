@@ -130,7 +130,7 @@ def main():
 
     # consecutive batches alternate over two HIP streams, as util.score_rows does (util.batch_streams): batch k+1's
     # opening kernels run under batch k's last layer.  cursor["lanes"] = 1 puts every batch on the current stream.
-    lanes = util.batch_streams(dev, 2)
+    lanes = util.batch_streams(dev, int(os.environ.get("DIGAT_BENCH_LANES", "2")))
     lane_scores = [torch.empty(B, dtype=torch.float32, device=dev) for _ in lanes]
     cursor["lanes"] = len(lanes)
 
