@@ -16,7 +16,13 @@
  *     scratch comes from the caller (`workspace`, size from the matching *_workspace_bytes);
  *   - inputs are never written; outputs may alias the `addend` argument where one exists;
  *   - returns DIGAT_OK (0) or a DIGAT_ERR_* code, never throws.  Eval-mode semantics
- *     (dropout = identity), i.e. what DIGAT.inference / model.eval() computes.
+ *     (dropout = identity), i.e. what DIGAT.inference / model.eval() computes;
+ *   - one host thread issues the calls of a process (one process per GPU): the library keeps a side stream with its
+ *     events and the launch profiler in process-wide state.  Calls on DIFFERENT streams may be in flight together as
+ *     long as each has its own workspace (digat_amd.util.score_rows alternates two).
+ * Environment, read once at load (development knobs; the setters below override them): DIGAT_SINGLE_STREAM=1 (no side
+ * stream), DIGAT_NO_SKIP=1 (no live-row lists), DIGAT_SPARSE_PER_NODE=<n> (threshold of DIGAT_XATTN_AUTO, default 12);
+ * DIGAT_XATTN_SKIP / DIGAT_TOPIC_SKIP are timing ablations that produce wrong results and must stay unset.
  */
 #ifndef DIGAT_HIP_H
 #define DIGAT_HIP_H
