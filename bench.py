@@ -278,6 +278,8 @@ def main():
                                   % ("6" if nprod == 6 else "6 for h, 3 for P and Q"),
                     "fp32_equivalent_tflops": rate / 1e12, "algorithmic_flops_per_launch": v["work"] / v["launches"],
                     "executed_flops_per_launch": nprod * v["work"] / v["launches"],
+                    "peak_note": "nominal dense bf16 peak (2.4 GHz); on random operands the chip holds about 1.9-2.0 GHz "
+                                 "(MI355X_MICROARCH.md), i.e. about 2.0 PFLOP/s",
                     "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
         if kind in ("proj", "linear"):
             return {"kernel": kind, "bound": "mfma", "achieved": rate / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
