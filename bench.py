@@ -366,6 +366,7 @@ def main():
         "config": {"workload": wl["label"], "projection": args.projection,
                    "user_side": "per row" if args.per_row_users else "once per impression (row_group index)",
                    "user_graph_eq8": getattr(model.graph_encoder, "user_xattn_mode", "dense") + " (chosen from the corpus: mean adjacency entries per node)",
+                   "news_graph_eq8": ("small-graph kernel (n <= 16)" if N <= 16 else getattr(model.graph_encoder, "news_xattn_mode", "dense")),
                    "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
                    "mean_candidates_per_impression": round(mean_cand, 3), "parallelism": f"dp{world} (row shards, no data-path collective)"},
         "rows_per_s": rows_total / elapsed,

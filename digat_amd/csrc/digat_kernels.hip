@@ -640,8 +640,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
                                        false);
         } else {
+            // larger news graphs (N = 26 / 65: the breadth-first SAG, a few entries per node) take the sparse kernel when the
+            // caller says so (flags bit 3); there is no device-side decision for this graph
             rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit,
-                            nullptr, nullptr, nullptr, DIGAT_XATTN_DENSE, nullptr, pq_x3);
+                            nullptr, nullptr, nullptr, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
+                            nullptr, pq_x3);
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;

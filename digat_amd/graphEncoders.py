@@ -78,6 +78,9 @@ class DIGAT(GraphEncoder):
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
         self.user_xattn_mode = "auto"
+        # ... and of news graphs of more than 16 nodes: "dense", "sparse" (DIGAT_NEWS_XATTN_SPARSE) or "auto" = dense until
+        # util.prepare_news_side has looked at the corpus (there is no device-side decision for this graph)
+        self.news_xattn_mode = "auto"
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -117,7 +120,8 @@ class DIGAT(GraphEncoder):
                                          "(call model.cuda()); there is no CPU path")
         P = _lib.Params()
         P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
-        P.flags = {"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode] | (4 if self.projection_mode == "bf16x6-pq3" else 0)
+        P.flags = ({"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode] | (4 if self.projection_mode == "bf16x6-pq3" else 0)
+                   | (8 if self.news_xattn_mode == "sparse" else 0))
         P.topic_node_embedding = self.topic_node_embedding.data_ptr()
         P.cand_K = self.candidate_attention.K.weight.data_ptr()
         P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
@@ -178,7 +182,7 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.projection_mode, self.user_xattn_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.projection_mode, self.user_xattn_mode, self.news_xattn_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))

@@ -112,6 +112,9 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
         U = dc.user_graph.shape[1]
         per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
         encoder.user_xattn_mode = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+    if getattr(encoder, "news_xattn_mode", None) == "auto" and N > 16 and dc.news_graph.numel() > 0:
+        per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
+        encoder.news_xattn_mode = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):

@@ -124,6 +124,10 @@ enum { DIGAT_XATTN_AUTO = 0, DIGAT_XATTN_DENSE = 1, DIGAT_XATTN_SPARSE = 2 };
  * feed the attention score — with the three leading bf16 products (hi*hi, mid*hi, hi*mid: relative error ~2^-16) instead
  * of six (~2^-24); h, which carries the values, keeps six.  A third fewer matrix instructions in the projection GEMM. */
 enum { DIGAT_PROJ_PQ_X3 = 4 };
+/* digat_params.flags bit 3: the NEWS graph's Eq. 8 with the sparse kernel too (news graphs of more than 16 nodes; smaller
+ * ones always take the wave-per-centre small-graph kernel).  SAG news graphs are breadth-first trees plus a few cross
+ * edges: 3-4 entries per node at N = 26 or 65. */
+enum { DIGAT_NEWS_XATTN_SPARSE = 8 };
 
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */
@@ -142,7 +146,7 @@ typedef struct digat_params {
     int32_t d;                /* news_embedding_dim                        */
     int32_t depth;            /* graph_depth                               */
     int32_t category_num;     /* C (topic_node_embedding rows)             */
-    int32_t flags;            /* bits 0-1: Eq. 8 of the user graph, DIGAT_XATTN_AUTO / _DENSE / _SPARSE; bit 2: DIGAT_PROJ_PQ_X3 (see below) */
+    int32_t flags;            /* bits 0-1: Eq. 8 of the user graph, DIGAT_XATTN_AUTO / _DENSE / _SPARSE; bit 2: DIGAT_PROJ_PQ_X3; bit 3: DIGAT_NEWS_XATTN_SPARSE (see below) */
     const float *topic_node_embedding;                      /* [C,d]        */
     const float *cand_K, *cand_Q, *cand_bQ;                 /* candidate_attention */
     const float *news_graph_W, *news_graph_b;               /* [d,2d], [d]  */

@@ -540,3 +540,28 @@ def test_three_product_pq_mode_stays_inside_the_metric_tolerance():
             assert float(((logit - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-4, mode
     assert err["bf16x6"] < 2e-6 and err["bf16x6-pq3"] < 5e-5, err
     assert err["bf16x6-pq3"] > err["bf16x6"]            # the mode is really on
+
+
+@pytest.mark.parametrize("neighbors,L", [(5, 2), (8, 2)], ids=["N26", "N65"])
+def test_news_graph_eq8_sparse_and_dense_agree_with_the_oracle(neighbors, L):
+    """News graphs of more than 16 nodes: the sparse kernel (DIGAT_NEWS_XATTN_SPARSE) and the tile + MFMA pair against the
+    oracle on the same batch of SAG-shaped graphs."""
+    from digat_amd import synthetic
+    N = synthetic.news_graph_size(neighbors, 2)
+    B, H, C, d = 96, 50, 17, 400
+    state = synthetic.make_state_dict(d, C, L, seed=61, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=62, isolated_news_rows=(3,))
+    with torch.no_grad():
+        wn, wu = O.encoder_forward(O.as_params(state), L, *O.batch_tensors(batch))
+    enc = make_encoder(state, N, H, C, d, L)
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    args = [to_dev(batch)[k] for k in keys]
+    out = {}
+    with torch.no_grad():
+        for mode in ("dense", "sparse"):
+            enc.news_xattn_mode = mode
+            out[mode] = enc(*args)
+            close(out[mode][0], wn, f"N={N}/{mode}: news ctx", rtol=2e-5, atol=2e-5)
+            close(out[mode][1], wu, f"N={N}/{mode}: user ctx", rtol=2e-5, atol=2e-5)
+    assert not torch.equal(out["dense"][0], out["sparse"][0])          # two different kernels really ran
