@@ -207,6 +207,24 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
     return xattn_core(X, A, r, W, bW, F1, F2, a, out, alpha_out, B, n, d, workspace, st);
 }
 
+int digat_xattn_fwd_mode(const float* X, const uint8_t* A, const float* ctx,
+                         const float* W, const float* bW, const float* F1, const float* F2,
+                         const float* F3, const float* b3, const float* a,
+                         float* out, int B, int n, int d, int mode,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (mode != DIGAT_XATTN_DENSE && mode != DIGAT_XATTN_SPARSE) return DIGAT_ERR_ARG;
+    if (!X || !A || !ctx || !W || !F1 || !F2 || !F3 || !a || !out || !workspace) return DIGAT_ERR_ARG;
+    if (B < 0 || n <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 4 || n > DIGAT_MAX_NODES) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_xattn_workspace_bytes(B, n, d)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* r = (float*)((char*)workspace + align_up((size_t)3 * B * n * d * 4, 256));
+    const int rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
+    if (rc) return rc;
+    return xattn_core(X, A, r, W, bW, F1, F2, a, out, nullptr, B, n, d, workspace, st, nullptr, nullptr, nullptr, nullptr, mode);
+}
+
 // ---- bf16x6 weight preparation + a directly callable linear (tests, micro-benchmarks) --------------
 size_t digat_split_weights_bytes(int rows, int K) {
     return (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;       // one 15 KB image per (80-row strip, K tile)

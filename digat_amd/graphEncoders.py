@@ -270,6 +270,16 @@ class DIGAT(GraphEncoder):
         ws = _lib.workspace(nbytes, dev, "xattn")
         W = getattr(self, f"{g}_graph_attention_W")[index]
         F3 = getattr(self, f"{g}_graph_attention_ffn3")[index]
+        mode = getattr(self, f"{g}_xattn_mode", "dense")
+        if mode == "sparse" and not return_alpha and n > 16 and d <= 1024:      # the caller knows the graphs are sparse
+            _lib.check(L.digat_xattn_fwd_mode(X.data_ptr(), adj.data_ptr(), ctx.data_ptr(), W.weight.data_ptr(), W.bias.data_ptr(),
+                                              getattr(self, f"{g}_graph_attention_ffn1")[index].weight.data_ptr(),
+                                              getattr(self, f"{g}_graph_attention_ffn2")[index].weight.data_ptr(),
+                                              F3.weight.data_ptr(), F3.bias.data_ptr(),
+                                              getattr(self, f"{g}_graph_attention_a")[index].weight.data_ptr(),
+                                              out.data_ptr(), B, n, d, 2, ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                       "digat_xattn_fwd_mode")
+            return out
         _lib.check(L.digat_xattn_fwd(X.data_ptr(), adj.data_ptr(), ctx.data_ptr(), W.weight.data_ptr(),
                                      W.bias.data_ptr(),
                                      getattr(self, f"{g}_graph_attention_ffn1")[index].weight.data_ptr(),
@@ -432,6 +442,8 @@ class _Ablation(GraphEncoder):
     compute_news_graph_context = DIGAT.compute_news_graph_context
     compute_user_graph_context = DIGAT.compute_user_graph_context
     _xattn = DIGAT._xattn
+    user_xattn_mode = "auto"      # Eq. 8 variant per graph for digat_xattn_fwd_mode ("auto" = dense until
+    news_xattn_mode = "auto"      # util.prepare_news_side has looked at the corpus)
 
     def _gat(self, g: str, index: int, X, A):
         """Vanilla GAT update layer (graphEncoders.py:493-519)."""

@@ -75,6 +75,14 @@ int digat_xattn_fwd(const float* X, const uint8_t* A, const float* ctx,
                     const float* F3, const float* b3, const float* a,
                     float* out, float* alpha_out, int B, int n, int d,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* The same without alpha_out and with the Eq. 8 variant named (DIGAT_XATTN_DENSE or DIGAT_XATTN_SPARSE, below): the sparse
+ * kernel visits only the adjacency entries (graphs with a few entries per node; n > 16, d <= 1024), results equal to
+ * fp32 summation order. */
+int digat_xattn_fwd_mode(const float* X, const uint8_t* A, const float* ctx,
+                         const float* W, const float* bW, const float* F1, const float* F2,
+                         const float* F3, const float* b3, const float* a,
+                         float* out, int B, int n, int d, int mode,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* The Eq. 8 pairwise part alone, on already-projected inputs: h = X W^T + bW, Q = X F2^T and
  * Pr = (ctx F3^T + b3) + X F1^T, i.e. K3 + K1 already summed in the reference's left-to-right order:

@@ -565,3 +565,29 @@ def test_news_graph_eq8_sparse_and_dense_agree_with_the_oracle(neighbors, L):
             close(out[mode][0], wn, f"N={N}/{mode}: news ctx", rtol=2e-5, atol=2e-5)
             close(out[mode][1], wu, f"N={N}/{mode}: user ctx", rtol=2e-5, atol=2e-5)
     assert not torch.equal(out["dense"][0], out["sparse"][0])          # two different kernels really ran
+
+
+def test_per_function_eq8_entry_with_the_sparse_kernel():
+    """digat_xattn_fwd_mode(DIGAT_XATTN_SPARSE) through DIGAT.compute_user_graph_embeddings: against the oracle's
+    cross_graph_attention and against the dense entry on MIND-shaped user graphs (one graph has a row without any entry)."""
+    from digat_amd import synthetic
+    B, N, H, C, d, L = 64, 10, 50, 17, 400, 1
+    state = synthetic.make_state_dict(d, C, L, seed=71, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=72, empty_history_rows=(2,))
+    batch["user_graph"][5, 3, :] = False
+    p = O.as_params(state)
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    with torch.no_grad():
+        Xu = O.user_nodes(p, tb["user_news_embedding"])
+        c_n = O.news_graph_context(p, tb["news_graph_embeddings"], tb["news_graph_mask"])
+        want = O.cross_graph_attention(p, "user", 0, Xu, tb["user_graph"], c_n)
+    enc = make_encoder(state, N, H, C, d, L)
+    dXu, dA, dc = Xu.to(_dev()), tb["user_graph"].to(_dev()), c_n.to(_dev())
+    with torch.no_grad():
+        enc.user_xattn_mode = "dense"
+        dense = enc.compute_user_graph_embeddings(0, dXu, dA, dc)
+        enc.user_xattn_mode = "sparse"
+        sparse = enc.compute_user_graph_embeddings(0, dXu, dA, dc)
+    close(dense, want, "dense entry", rtol=1e-5, atol=1e-5)
+    close(sparse, want, "sparse entry", rtol=1e-5, atol=1e-5)
+    assert not torch.equal(dense, sparse)
