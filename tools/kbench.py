@@ -60,6 +60,36 @@ def bench_xattn(B=1024, n=67, d=400, density=None):
           f"{bytes_b/med/1e6:.0f} GB/s algorithmic  ({bytes_b/1e6:.0f} MB)")
 
 
+def bench_xattn_entry(B=1024, n=67, d=400):
+    """digat_xattn_fwd_mode (K3 + projections + Eq. 8) on MIND-shaped user graphs: the dense pair against the sparse kernel."""
+    from digat_amd import synthetic
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    batch = synthetic.make_encoder_batch(B, 10, 50, n - 50, d, seed=0)
+    A = torch.from_numpy(batch["user_graph"]).to(dev).view(torch.uint8)
+    X = torch.randn(B, n, d, device=dev, generator=g)
+    ctx = torch.randn(B, d, device=dev, generator=g)
+    W, F1, F2, F3 = (torch.randn(d, d, device=dev, generator=g) / d ** 0.5 for _ in range(4))
+    bW, b3 = torch.randn(d, device=dev, generator=g) * 0.1, torch.randn(d, device=dev, generator=g) * 0.1
+    a = torch.randn(d, device=dev, generator=g) * 0.1
+    L = _lib.lib()
+    nbytes = L.digat_xattn_workspace_bytes(B, n, d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    outs = {}
+    for name, mode in (("dense", 1), ("sparse", 2)):
+        out = torch.empty_like(X)
+
+        def run():
+            _lib.check(L.digat_xattn_fwd_mode(X.data_ptr(), A.data_ptr(), ctx.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
+                                              F2.data_ptr(), F3.data_ptr(), b3.data_ptr(), a.data_ptr(), out.data_ptr(), B, n, d, mode,
+                                              ws.data_ptr(), nbytes, _lib.stream_ptr()), "xattn_fwd_mode")
+        med, best = timeit(run)
+        outs[name] = out
+        print(f"digat_xattn_fwd_mode {name:6s} B={B} n={n} d={d} (fp32 MFMA projections of all rows included): median {med*1e3:.1f} us  best {best*1e3:.1f} us")
+    print(f"   max |dense - sparse| = {float((outs['dense'] - outs['sparse']).abs().max()):.2e}"
+          f"   adjacency entries per node {float(batch['user_graph'].sum() / (B * n)):.2f}")
+
+
 def bench_linear(M=68608, N=400, K=400):
     dev = torch.device("cuda:0")
     x = torch.randn(M, K, device=dev)
@@ -171,6 +201,8 @@ if __name__ == "__main__":
     nums = [int(v) for v in sys.argv[2:]]
     if what == "xattn":
         bench_xattn(*nums)
+    elif what == "xattn-entry":
+        bench_xattn_entry(*nums)
     elif what == "xattn-mind":
         bench_xattn(*nums, density="mind")
     elif what == "msa":
