@@ -179,7 +179,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     const int* skip_if = nullptr;
     if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
         const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
-                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4,
+                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
                             listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr};
         const int rcs = launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
@@ -417,7 +417,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
-                              float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups) {
+                              float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
+                              const float* Xg0) {
+    const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
@@ -437,8 +439,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         return launch_gemm(g, sq);
     };
-    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq) -> int {
-        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq);
+    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr) -> int {
+        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
@@ -538,16 +540,18 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         const digat_layer_params& lu = p->user[0];
         const size_t ndg = (size_t)G * U * d;
         const size_t nd = (size_t)B * U * d;
-        float* Xg = Xu[1];                                  // group nodes: free until layer 0's output is written
+        float* Xg = xu0_grouped ? const_cast<float*>(Xg0) : Xu[1];     // group nodes: built by the caller, or here (Xu[1] is free until layer 0 writes it)
         float* h0 = (float*)xws;
         float* P0 = h0 + ndg;                               // behind the groups' h in the h slot (2 ndg <= nd)
         float* Q0 = h0 + 2 * nd;
         const long total4 = (long)ndg / 4;
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq, (const float4*)ue_groups,
-                           (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
-        DIGAT_CHECK_LAUNCH();
+        if (!xu0_grouped) {
+            hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq, (const float4*)ue_groups,
+                               (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
+            DIGAT_CHECK_LAUNCH();
+        }
         GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
         gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
         gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = Q0;
@@ -582,7 +586,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     }
     rc = from_c_n(0, st);
     if (rc) return rc;
-    rc = user_ctx_tail(Xu[0], nullptr, st);        // c_u (:192)
+    rc = user_ctx_tail(xu0_grouped ? Xg0 : Xu[0], nullptr, st, xu0_grouped ? row_group : nullptr);        // c_u (:192)
     if (rc) return rc;
     const float* xn_cur = Xn_in;
     int un = 0, nn = 0;
@@ -620,8 +624,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = DIGAT_OK;
             if (sparse_mode != DIGAT_XATTN_DENSE && d / 4 <= 256) {
                 // P' = K1 (the groups' P0) + K3 (this layer's r_user) is formed inside the kernel: nothing is expanded
-                const SparseArgs sg{P0, Q0, h0, Xu[0], lu.a, Au, Xu[1], r_user, row_group, nullptr,
-                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, nullptr, nullptr};
+                const SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, nullptr,
+                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, xu0_grouped ? 1 : 0,
+                                    // Xu[0] was never written: the rows of dead nodes, which layer 1 will not write there and
+                                    // the topic pooling after it reads (weight 0, but 0 * NaN = NaN), get X_i now
+                                    (xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
+                                    nullptr, nullptr};
                 rc = launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
@@ -746,14 +754,22 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     int* live_ws = (int*)((char*)xws_news + digat_xattn_workspace_bytes(B, N, d));
 
     int rc;
+    const bool folded = p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W;
+    // Rows of one impression share the user nodes.  When every reader of the layer-0 nodes can go through the group index
+    // (the sparse Eq. 8 kernel and the topic pooling can; the dense tile / aggregation kernels cannot) they are built once
+    // per GROUP: 3 MB instead of a 110 MB expansion that the first two kernels would read back.
+    const bool xu0_grouped = folded && row_group && L > 0 && (p->flags & 3) == DIGAT_XATTN_SPARSE && d / 4 <= 256 && U > 16 && 3 * (long)G <= B;
     // user graph nodes = [history | topic nodes]  (:191)
+    float* const Xg0 = xu0_grouped ? (float*)xws + 2 * (size_t)G * U * d : nullptr;      // behind the groups' h and P in the h slot (3 G <= B)
     {
-        const long total4 = (long)B * U * (d / 4);
+        const long nrows = xu0_grouped ? G : B;
+        const long total4 = nrows * U * (d / 4);
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)H * d * 8 + (double)C * d * 4), st);
+        ProfScope prof(DIGAT_KERNEL_GLUE, (double)nrows * ((double)H * d * 8 + (double)C * d * 4), st);
         hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue,
-                           (const float4*)p->topic_node_embedding, (float4*)Xu[0], (long)B, H, C, d / 4, row_group);
+                           (const float4*)p->topic_node_embedding, (float4*)(xu0_grouped ? Xg0 : Xu[0]), nrows, H, C, d / 4,
+                           xu0_grouped ? (const int*)nullptr : row_group);
         DIGAT_CHECK_LAUNCH();
     }
     // c_n: given (inference, :189) or computed (forward, :180); it lives in out_news from here on
@@ -765,9 +781,9 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                                 nullptr, out_news, B, N, d, cws, cws_bytes, stream);
         if (rc) return rc;
     }
-    if (p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)
+    if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,

@@ -591,3 +591,38 @@ def test_per_function_eq8_entry_with_the_sparse_kernel():
     close(dense, want, "dense entry", rtol=1e-5, atol=1e-5)
     close(sparse, want, "sparse entry", rtol=1e-5, atol=1e-5)
     assert not torch.equal(dense, sparse)
+
+
+def test_uninitialised_workspace_cannot_reach_the_outputs():
+    """Rows of dead nodes are skipped in layers >= 1 and, with the layer-0 nodes built once per group, parts of the node
+    buffers are never written by the projections: whatever the scratch held before must not matter (the topic pooling
+    multiplies EVERY history row by its weight, and 0 * NaN = NaN).  Every cached workspace is filled with NaN bit patterns
+    before a grouped and a per-row run; both must come out finite and equal, and equal to a run on clean scratch."""
+    from digat_amd import _lib, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=60, mean_candidates=30.0,
+                               max_candidates=80, seed=81)
+    corpus = synthetic.make_corpus(spec)
+    L = 3
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=82, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 512)
+    clean = util.score_rows(model, dc, 0, dc.rows, 512)           # also sizes the workspaces
+
+    def poison():
+        torch.cuda.synchronize()
+        for buf in _lib._workspaces.values():
+            buf.fill_(255)                                            # 0xFFFFFFFF = NaN
+        torch.cuda.synchronize()
+    poison()
+    grouped = util.score_rows(model, dc, 0, dc.rows, 512)
+    poison()
+    per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
+    assert torch.isfinite(grouped).all() and torch.isfinite(per_row).all()
+    assert torch.equal(grouped, clean) and torch.equal(per_row, clean)
