@@ -60,12 +60,15 @@ def bench_xattn(B=1024, n=67, d=400, density=None):
           f"{bytes_b/med/1e6:.0f} GB/s algorithmic  ({bytes_b/1e6:.0f} MB)")
 
 
-def bench_xattn_entry(B=1024, n=67, d=400):
+def bench_xattn_entry(B=1024, n=67, d=400, per_node=0):
     """digat_xattn_fwd_mode (K3 + projections + Eq. 8) on MIND-shaped user graphs: the dense pair against the sparse kernel."""
     from digat_amd import synthetic
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     batch = synthetic.make_encoder_batch(B, 10, 50, n - 50, d, seed=0)
+    if per_node > 0:       # random graphs with about per_node entries per node (self loops included) instead of MIND-shaped ones
+        rnd = torch.rand(B, n, n, generator=torch.Generator().manual_seed(1)) < (per_node - 1) / (n - 1)
+        batch["user_graph"] = (rnd | torch.eye(n, dtype=torch.bool)[None]).numpy()
     A = torch.from_numpy(batch["user_graph"]).to(dev).view(torch.uint8)
     X = torch.randn(B, n, d, device=dev, generator=g)
     ctx = torch.randn(B, d, device=dev, generator=g)
