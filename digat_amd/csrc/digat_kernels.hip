@@ -418,7 +418,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
-                              const float* Xg0) {
+                              const float* Xg0, const float* news_hpq0) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
@@ -529,6 +529,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gp.w[2] = ln.F2; gp.bias[2] = nullptr; gp.y[2] = hn + 2 * ndn;
         gp.nsegs = 3;
         gp.x3_segs = pq_x3 ? 6 : 0;
+        gp.m_dispatch = 1 << 30;       // always the large-M kernel: a row's bits then do not depend on the batch it sits in
+                                       // (digat_news_project0 makes the same launch per news, once)
         gp.wsplit = (const unsigned short*)ln.wsplit;
         return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
     };
@@ -580,7 +582,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     if (group_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO)) {
         if (hipEventRecord(side->early, side->s) != hipSuccess) return DIGAT_ERR_LAUNCH;
     }
-    if (news_early) {
+    if (news_early && !news_hpq0) {      // news_hpq0: the caller kept layer 0's news projections per news (digat_news_project0)
         rc = news_project(0, Xn_in, side ? side->s : st);
         if (rc) return rc;
     }
@@ -661,7 +663,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
             const size_t ndn = (size_t)B * N * d;
-            float* hn = (float*)xws_news;
+            const float* hn = (i == 0 && news_hpq0) ? news_hpq0 : (const float*)xws_news;
             float* alpha_n = (float*)((char*)xws_news + align_up(3 * ndn * 4, 256) + align_up((size_t)B * d * 4, 256));
             rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
                                        false);
@@ -720,7 +722,8 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
 static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                             const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                             const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
-                            void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G) {
+                            void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
+                            const float* news_hpq0 = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -783,7 +786,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -843,10 +846,11 @@ size_t digat_encoder_grouped_workspace_bytes(int B, int N, int H, int C, int d, 
            + align_up((size_t)B * (C + 1), 256) + align_up((size_t)B * H * 8, 256);
 }
 
-int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
-                              const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
-                              const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
-                              int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream) {
+static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                                    const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
+                                    const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
+                                    int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream,
+                                    const float* news_hpq0) {
     if (!p || !ue_g || !Au_g || !cat_mask_g || !cat_idx_g || !row_group || !workspace || G <= 0) return DIGAT_ERR_ARG;
     const int d = p->d, C = p->category_num, U = H + C;
     if (!p->cand_fold_W || !p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;   // grouped = folded path
@@ -869,7 +873,42 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G);
+                            base, stream, row_group, G, news_hpq0);
+}
+
+int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                              const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
+                              const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
+                              int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
+                                    workspace, workspace_bytes, stream, nullptr);
+}
+
+int digat_encoder_fwd_grouped_cached(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
+                                     const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
+                                     const int32_t* row_group, const float* c_n0, const float* news_hpq0, float* out_news,
+                                     float* out_user, int B, int G, int N, int H, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
+                                    workspace, workspace_bytes, stream, news_hpq0);
+}
+
+int digat_news_project0(const digat_params* p, const float* Xn, float* hpq, int M, int N, void* stream) {
+    if (!p || !Xn || !hpq || M < 0 || N <= 0 || p->depth <= 0) return DIGAT_ERR_ARG;
+    const int d = p->d;
+    if (d <= 0 || d % 4 || (long)M * N > 0x7fffffffL / 4) return DIGAT_ERR_SHAPE;
+    if (M == 0) return DIGAT_OK;
+    const digat_layer_params& ln = p->news[0];
+    const size_t ndn = (size_t)M * N * d;
+    // exactly the launch the encoder makes for layer 0 of the news graph (rows are independent of the batch they sit in)
+    GemmArgs gp = gemm_plain(Xn, d, ln.W, ln.bW, hpq, d, M * N, d, d, 0);
+    gp.w[1] = ln.F1; gp.bias[1] = nullptr; gp.y[1] = hpq + ndn;
+    gp.w[2] = ln.F2; gp.bias[2] = nullptr; gp.y[2] = hpq + 2 * ndn;
+    gp.nsegs = 3;
+    gp.x3_segs = (p->flags & DIGAT_PROJ_PQ_X3) ? 6 : 0;
+    gp.wsplit = (const unsigned short*)ln.wsplit;
+    gp.m_dispatch = 1 << 30;
+    return launch_gemm(gp, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
 
 static double g_prof_last_live_fraction = -1.0;

@@ -325,8 +325,21 @@ class DIGAT(GraphEncoder):
                                        B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_encoder_fwd")
         return out_n, out_u
 
+    def project_news_layer0(self, news_graph_embeddings):
+        """[h|P|Q] of layer 0 of the news graph for M news graphs ([M,N,d] -> [3,M,N,d]): they depend on the news alone, so a
+        driver can keep them per news next to the news representations and c_n0 (``util.prepare_news_side``) and hand the
+        batch's rows to ``inference_grouped(news_hpq0=...)``.  Same launch, same bits as inside the encoder."""
+        X = _lib.f32(news_graph_embeddings)
+        dev = _lib.require_device(X)
+        M, N, d = X.shape
+        out = torch.empty((3, M, N, d), dtype=torch.float32, device=dev)
+        if M:
+            _lib.check(_lib.lib().digat_news_project0(self._params(), X.data_ptr(), out.data_ptr(), M, N, _lib.stream_ptr()),
+                       "digat_news_project0")
+        return out
+
     def inference_grouped(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
-                          user_category_mask, user_category_indices, row_group, news_graph_context):
+                          user_category_mask, user_category_indices, row_group, news_graph_context, news_hpq0=None):
         """``inference`` for rows that share users (not in the reference: its driver expands the user tensors per
         row, util.py:57-67).  The four user tensors are given once per GROUP ([G,...]) and ``row_group`` [B] maps
         each row to its group; results are bit-identical to ``inference`` on the expanded tensors."""
@@ -352,6 +365,16 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
+        if news_hpq0 is not None:
+            hpq = _lib.f32(news_hpq0)
+            if tuple(hpq.shape) != (3, B, N, d):
+                raise ValueError("news_hpq0 must be [3, B, N, d] (project_news_layer0 of the batch's candidates)")
+            _lib.check(L.digat_encoder_fwd_grouped_cached(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(),
+                                                          Au.data_ptr(), cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(),
+                                                          hpq.data_ptr(), out_n.data_ptr(), out_u.data_ptr(), B, G, N, H,
+                                                          ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                       "digat_encoder_fwd_grouped_cached")
+            return out_n, out_u
         _lib.check(L.digat_encoder_fwd_grouped(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
                                                cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(), out_n.data_ptr(),
                                                out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),

@@ -85,11 +85,13 @@ class Model(nn.Module):
 
 
     def inference_grouped(self, user_news_embedding, user_graph, user_category_mask, user_category_indices, row_group,
-                          candidate_news_embedding, news_graph, news_graph_mask, c_n0):
-        """``inference`` with the user tensors given once per impression ([G,...]) + ``row_group`` [B]."""
+                          candidate_news_embedding, news_graph, news_graph_mask, c_n0, news_hpq0=None):
+        """``inference`` with the user tensors given once per impression ([G,...]) + ``row_group`` [B]; ``news_hpq0``:
+        the candidates' rows of the per-news layer-0 projection table (``DIGAT.project_news_layer0``), optional."""
+        kw = {} if news_hpq0 is None else {"news_hpq0": news_hpq0}
         news_rep, user_rep = self.graph_encoder.inference_grouped(candidate_news_embedding, news_graph, news_graph_mask,
                                                                   user_news_embedding, user_graph, user_category_mask,
-                                                                  user_category_indices, row_group, c_n0)
+                                                                  user_category_indices, row_group, c_n0, **kw)
         B, d = news_rep.shape
         logits = torch.empty(B, dtype=torch.float32, device=news_rep.device)
         if B:

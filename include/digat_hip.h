@@ -223,6 +223,20 @@ int digat_encoder_fwd_grouped(const digat_params* params,
                               const float* news_graph_context, float* out_news_context, float* out_user_context,
                               int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Layer 0's projections of the NEWS graph ([h|P|Q] = X_n [W|ffn1|ffn2]^T of news[0]) depend on the candidate news alone, like
+ * the news representations and c_n0 the reference's driver caches per news (util.py:24-44).  digat_news_project0 computes
+ * them for M news graphs: Xn [M,N,d] -> hpq [3][M,N,d] (the launch the encoder itself makes; M*N >= 2048 rows for the bf16x6
+ * kernel).  digat_encoder_fwd_grouped_cached takes the batch's rows of that table (news_hpq0 [3][B,N,d], gathered by the
+ * caller; NULL = compute as usual) and skips the projection GEMM of layer 0 when N <= 16.  Results are bit-identical. */
+int digat_news_project0(const digat_params* params, const float* Xn, float* hpq, int M, int N, void* stream);
+int digat_encoder_fwd_grouped_cached(const digat_params* params,
+                                     const float* news_graph_embeddings, const uint8_t* news_graph, const uint8_t* news_graph_mask,
+                                     const float* user_news_embedding_g, const uint8_t* user_graph_g,
+                                     const uint8_t* user_category_mask_g, const int64_t* user_category_indices_g,
+                                     const int32_t* row_group, const float* news_graph_context, const float* news_hpq0,
+                                     float* out_news, float* out_user, int B, int G, int N, int H,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* H1: Model.inference's last line (model.py:89): logits[b] = sum_c user_ctx[b,c] * news_ctx[b,c]. */
 int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits, int B, int d, void* stream);
 

@@ -626,3 +626,30 @@ def test_uninitialised_workspace_cannot_reach_the_outputs():
     per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
     assert torch.isfinite(grouped).all() and torch.isfinite(per_row).all()
     assert torch.equal(grouped, clean) and torch.equal(per_row, clean)
+
+
+def test_cached_news_projections_reproduce_the_in_batch_bits():
+    """Layer 0's [h|P|Q] of the news graph kept per news (DIGAT.project_news_layer0, util.prepare_news_side) and gathered per
+    batch, against the same scores with the projection GEMM inside every call — ragged last batch included."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=1500, sag_neighbors=3, sag_hops=2, impressions=70, mean_candidates=30.0,
+                               max_candidates=80, seed=91)
+    corpus = synthetic.make_corpus(spec)
+    L = 2
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=92, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 512)
+    assert dc.news_hpq0 is not None and tuple(dc.news_hpq0.shape) == (3, 1500, spec.news_graph_size, spec.embedding_dim)
+    with_table = util.score_rows(model, dc, 0, dc.rows, 512)
+    table, dc.news_hpq0 = dc.news_hpq0, None
+    without = util.score_rows(model, dc, 0, dc.rows, 512)
+    per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
+    dc.news_hpq0 = table
+    assert torch.equal(with_table, without) and torch.equal(with_table, per_row)
