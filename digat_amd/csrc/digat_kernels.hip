@@ -418,7 +418,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
-                              const float* Xg0, const float* news_hpq0) {
+                              const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
@@ -553,6 +553,19 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq, (const float4*)ue_groups,
                                (const float4*)p->topic_node_embedding, (float4*)Xg, (long)G, H, C, d / 4, (const int*)nullptr);
             DIGAT_CHECK_LAUNCH();
+        }
+        if (hist_hpq0 && topic_hpq0 && (long)B * U >= 2048) {
+            // [h|P|Q] of a history node depend on that news alone and those of a topic node on nothing: the caller keeps them
+            // per news / per topic (digat_user_project0) and hands over the groups' history rows; the projection GEMM of the
+            // groups becomes three assemblies [history rows | topic rows] (same kernel, same bits: rows are independent)
+            float* dst[3] = {h0, P0, Q0};
+            for (int t = 0; t < 3; ++t) {
+                hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq,
+                                   (const float4*)(hist_hpq0 + (size_t)t * G * H * d), (const float4*)(topic_hpq0 + (size_t)t * C * d),
+                                   (float4*)dst[t], (long)G, H, C, d / 4, (const int*)nullptr);
+                DIGAT_CHECK_LAUNCH();
+            }
+            return DIGAT_OK;
         }
         GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
         gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = P0;
@@ -723,7 +736,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                             const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
                             void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
-                            const float* news_hpq0 = nullptr) {
+                            const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -786,7 +799,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -850,7 +863,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
                                     const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
                                     const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
                                     int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream,
-                                    const float* news_hpq0) {
+                                    const float* news_hpq0, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr) {
     if (!p || !ue_g || !Au_g || !cat_mask_g || !cat_idx_g || !row_group || !workspace || G <= 0) return DIGAT_ERR_ARG;
     const int d = p->d, C = p->category_num, U = H + C;
     if (!p->cand_fold_W || !p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;   // grouped = folded path
@@ -873,7 +886,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G, news_hpq0);
+                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0);
 }
 
 int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
@@ -886,11 +899,30 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
 
 int digat_encoder_fwd_grouped_cached(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                                      const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
-                                     const int32_t* row_group, const float* c_n0, const float* news_hpq0, float* out_news,
+                                     const int32_t* row_group, const float* c_n0, const float* news_hpq0,
+                                     const float* hist_hpq0, const float* topic_hpq0, float* out_news,
                                      float* out_user, int B, int G, int N, int H, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+    if ((hist_hpq0 == nullptr) != (topic_hpq0 == nullptr)) return DIGAT_ERR_ARG;
     return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
-                                    workspace, workspace_bytes, stream, news_hpq0);
+                                    workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0);
+}
+
+int digat_user_project0(const digat_params* p, const float* X, float* hpq, int M, void* stream) {
+    if (!p || !X || !hpq || M < 0 || p->depth <= 0) return DIGAT_ERR_ARG;
+    const int d = p->d;
+    if (d <= 0 || d % 4) return DIGAT_ERR_SHAPE;
+    if (M == 0) return DIGAT_OK;
+    const digat_layer_params& lu = p->user[0];
+    const size_t nd = (size_t)M * d;
+    GemmArgs gg = gemm_plain(X, d, lu.W, lu.bW, hpq, d, M, d, d, 0);       // the groups' projection launch of layer 0, row by row
+    gg.w[1] = lu.F1; gg.bias[1] = nullptr; gg.y[1] = hpq + nd;
+    gg.w[2] = lu.F2; gg.bias[2] = nullptr; gg.y[2] = hpq + 2 * nd;
+    gg.nsegs = 3;
+    gg.x3_segs = (p->flags & DIGAT_PROJ_PQ_X3) ? 6 : 0;
+    gg.wsplit = (const unsigned short*)lu.wsplit;
+    gg.m_dispatch = 1 << 30;                                               // the large-M kernel whatever M is (C topic rows)
+    return launch_gemm(gg, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
 
 int digat_news_project0(const digat_params* p, const float* Xn, float* hpq, int M, int N, void* stream) {

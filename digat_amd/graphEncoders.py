@@ -338,8 +338,21 @@ class DIGAT(GraphEncoder):
                        "digat_news_project0")
         return out
 
+    def project_user_layer0(self, rows):
+        """[h|P|Q] of layer 0 of the USER graph for M node embeddings ([M,d] -> [3,M,d]): row-wise, so they can be kept per
+        news (history nodes) and per topic (``self.topic_node_embedding``) — see ``util.prepare_news_side``."""
+        X = _lib.f32(rows)
+        dev = _lib.require_device(X)
+        M, d = X.shape
+        out = torch.empty((3, M, d), dtype=torch.float32, device=dev)
+        if M:
+            _lib.check(_lib.lib().digat_user_project0(self._params(), X.data_ptr(), out.data_ptr(), M, _lib.stream_ptr()),
+                       "digat_user_project0")
+        return out
+
     def inference_grouped(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
-                          user_category_mask, user_category_indices, row_group, news_graph_context, news_hpq0=None):
+                          user_category_mask, user_category_indices, row_group, news_graph_context, news_hpq0=None,
+                          hist_hpq0=None, topic_hpq0=None):
         """``inference`` for rows that share users (not in the reference: its driver expands the user tensors per
         row, util.py:57-67).  The four user tensors are given once per GROUP ([G,...]) and ``row_group`` [B] maps
         each row to its group; results are bit-identical to ``inference`` on the expanded tensors."""
@@ -365,14 +378,20 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
-        if news_hpq0 is not None:
-            hpq = _lib.f32(news_hpq0)
-            if tuple(hpq.shape) != (3, B, N, d):
-                raise ValueError("news_hpq0 must be [3, B, N, d] (project_news_layer0 of the batch's candidates)")
+        if news_hpq0 is not None or hist_hpq0 is not None:
+            hpq = hh = th = None
+            if news_hpq0 is not None:
+                hpq = _lib.f32(news_hpq0)
+                if tuple(hpq.shape) != (3, B, N, d):
+                    raise ValueError("news_hpq0 must be [3, B, N, d] (project_news_layer0 of the batch's candidates)")
+            if hist_hpq0 is not None:
+                hh, th = _lib.f32(hist_hpq0), _lib.f32(topic_hpq0)
+                if tuple(hh.shape) != (3, G, H, d) or tuple(th.shape) != (3, C, d):
+                    raise ValueError("hist_hpq0 must be [3, G, H, d] and topic_hpq0 [3, C, d] (project_user_layer0)")
             _lib.check(L.digat_encoder_fwd_grouped_cached(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(),
                                                           Au.data_ptr(), cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(),
-                                                          hpq.data_ptr(), out_n.data_ptr(), out_u.data_ptr(), B, G, N, H,
-                                                          ws.data_ptr(), nbytes, _lib.stream_ptr()),
+                                                          _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), out_n.data_ptr(),
+                                                          out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),
                        "digat_encoder_fwd_grouped_cached")
             return out_n, out_u
         _lib.check(L.digat_encoder_fwd_grouped(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),

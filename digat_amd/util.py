@@ -42,6 +42,8 @@ class DeviceCorpus:
     SA_news_representations: Optional[torch.Tensor] = None   # [news_num, N, d] (util.py:36)
     c_n0: Optional[torch.Tensor] = None                      # [news_num, d]    (util.py:37-44)
     news_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, N, d]: layer 0's [h|P|Q] of every news graph
+    user_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, d]: layer 0's user-graph [h|P|Q] of every news as a history node
+    topic_hpq0: Optional[torch.Tensor] = None                # [3, C, d]: ... of the topic nodes
 
     @classmethod
     def from_numpy(cls, corpus, device) -> "DeviceCorpus":
@@ -117,6 +119,12 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
                 e = min(s + chunk, news_num)
                 table[:, s:e] = encoder.project_news_layer0(dc.SA_news_representations[s:e])
         dc.news_hpq0 = table
+    # the user graph's layer-0 projections are row-wise: per news (a history node is a news) and per topic node
+    dc.user_hpq0 = dc.topic_hpq0 = None
+    if hasattr(encoder, "project_user_layer0") and getattr(encoder, "graph_depth", 0) > 0 and d % 4 == 0:
+        with torch.no_grad():
+            dc.user_hpq0 = encoder.project_user_layer0(dc.news_embedding)
+            dc.topic_hpq0 = encoder.project_user_layer0(encoder.topic_node_embedding.detach())
     # Eq. 8 of the user graph: the corpus is known here, so the sparse / dense choice the library would otherwise make on
     # the device per batch (both variants launched, one returning at once) is made once, on the host, from the mean
     # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" is left alone.
@@ -190,7 +198,8 @@ class GroupedBatchPipeline:
                         news_graph=torch.empty((B, N, N), dtype=dc.news_graph.dtype, device=dev),
                         news_mask=torch.empty((B, N), dtype=dc.news_graph_mask.dtype, device=dev),
                         c_n0=torch.empty((B, d), dtype=torch.float32, device=dev),
-                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None else None))
+                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None else None),
+                        hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None))
         self.sets = [bufs(), bufs()]
         uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
         for s, e in self.batches:
@@ -234,6 +243,11 @@ class GroupedBatchPipeline:
             torch.index_select(dc.news_graph, 0, cand, out=b["news_graph"][:n])
             torch.index_select(dc.news_graph_mask, 0, cand, out=b["news_mask"][:n])
             torch.index_select(dc.c_n0, 0, cand, out=b["c_n0"][:n])
+            if b["hist_hpq"] is not None:
+                hh = b["hist_hpq"][:3 * G * H * d].view(3, G * H, d)
+                flat = b["hist"][:G].reshape(-1)
+                for t in range(3):
+                    torch.index_select(dc.user_hpq0[t], 0, flat, out=hh[t])
             if b["hpq"] is not None:
                 N = dc.news_graph.shape[1]
                 hpq = b["hpq"][:3 * n * N * d].view(3, n, N, d)              # contiguous [3, n, N, d] for this batch's n rows
@@ -254,9 +268,12 @@ class GroupedBatchPipeline:
         torch.cuda.current_stream(self.dev).wait_event(self.ready[par])
         out = (b["user_rep"][:G], b["user_graph"][:G], b["cat_mask"][:G], b["cat_idx"][:G], row_group,
                b["sa"][:n], b["news_graph"][:n], b["news_mask"][:n], b["c_n0"][:n])
-        if b["hpq"] is not None:
-            N_, d_ = b["sa"].shape[1], b["sa"].shape[2]
-            out = out + (b["hpq"][:3 * n * N_ * d_].view(3, n, N_, d_),)
+        N_, d_ = b["sa"].shape[1], b["sa"].shape[2]
+        H_ = b["hist"].shape[1]
+        news_hpq = b["hpq"][:3 * n * N_ * d_].view(3, n, N_, d_) if b["hpq"] is not None else None
+        hist_hpq = b["hist_hpq"][:3 * G * H_ * d_].view(3, G, H_, d_) if b["hist_hpq"] is not None else None
+        if news_hpq is not None or hist_hpq is not None:
+            out = out + (news_hpq, hist_hpq, self.dc.topic_hpq0 if hist_hpq is not None else None)
         return out
 
     def scored(self, k):

@@ -229,11 +229,19 @@ int digat_encoder_fwd_grouped(const digat_params* params,
  * kernel).  digat_encoder_fwd_grouped_cached takes the batch's rows of that table (news_hpq0 [3][B,N,d], gathered by the
  * caller; NULL = compute as usual) and skips the projection GEMM of layer 0 when N <= 16.  Results are bit-identical. */
 int digat_news_project0(const digat_params* params, const float* Xn, float* hpq, int M, int N, void* stream);
+/* The USER graph's layer-0 projections are row-wise too: those of a history node depend on that news alone, those of a topic
+ * node on nothing.  digat_user_project0: X [M,d] -> hpq [3][M,d] with user[0]'s [W|ffn1|ffn2] (for the news table, M = number
+ * of news; for the topic table, X = topic_node_embedding, M = C).  The cached entry takes the groups' history rows
+ * hist_hpq0 [3][G,H,d] (gathered by the caller with the history ids) and topic_hpq0 [3][C,d] — both or neither — and assembles
+ * the groups' [h|P|Q] from them instead of running the projection GEMM (used when B*U >= 2048: below that the in-batch
+ * launch is another kernel).  Bit-identical. */
+int digat_user_project0(const digat_params* params, const float* X, float* hpq, int M, void* stream);
 int digat_encoder_fwd_grouped_cached(const digat_params* params,
                                      const float* news_graph_embeddings, const uint8_t* news_graph, const uint8_t* news_graph_mask,
                                      const float* user_news_embedding_g, const uint8_t* user_graph_g,
                                      const uint8_t* user_category_mask_g, const int64_t* user_category_indices_g,
                                      const int32_t* row_group, const float* news_graph_context, const float* news_hpq0,
+                                     const float* hist_hpq0, const float* topic_hpq0,
                                      float* out_news, float* out_user, int B, int G, int N, int H,
                                      void* workspace, size_t workspace_bytes, void* stream);
 

@@ -629,8 +629,9 @@ def test_uninitialised_workspace_cannot_reach_the_outputs():
 
 
 def test_cached_news_projections_reproduce_the_in_batch_bits():
-    """Layer 0's [h|P|Q] of the news graph kept per news (DIGAT.project_news_layer0, util.prepare_news_side) and gathered per
-    batch, against the same scores with the projection GEMM inside every call — ragged last batch included."""
+    """Layer 0's [h|P|Q] kept per news — of the news graphs (DIGAT.project_news_layer0) and of the news as history nodes of
+    the user graph, plus the topic nodes (project_user_layer0) — and gathered per batch (util.prepare_news_side), against the
+    same scores with the projection GEMMs inside every call; ragged last batch included."""
     from digat_amd import synthetic, util
     from digat_amd.model import Model, PrecomputedNewsEncoder
     spec = synthetic.SynthSpec(news_num=1500, sag_neighbors=3, sag_hops=2, impressions=70, mean_candidates=30.0,
@@ -647,9 +648,13 @@ def test_cached_news_projections_reproduce_the_in_batch_bits():
     dc = util.DeviceCorpus.from_numpy(corpus, _dev())
     util.prepare_news_side(model.graph_encoder, dc, 512)
     assert dc.news_hpq0 is not None and tuple(dc.news_hpq0.shape) == (3, 1500, spec.news_graph_size, spec.embedding_dim)
-    with_table = util.score_rows(model, dc, 0, dc.rows, 512)
-    table, dc.news_hpq0 = dc.news_hpq0, None
+    assert tuple(dc.user_hpq0.shape) == (3, 1500, spec.embedding_dim) and tuple(dc.topic_hpq0.shape) == (3, spec.category_num, spec.embedding_dim)
+    with_tables = util.score_rows(model, dc, 0, dc.rows, 512)
+    saved = (dc.news_hpq0, dc.user_hpq0, dc.topic_hpq0)
+    dc.user_hpq0 = dc.topic_hpq0 = None
+    news_only = util.score_rows(model, dc, 0, dc.rows, 512)
+    dc.news_hpq0 = None
     without = util.score_rows(model, dc, 0, dc.rows, 512)
     per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
-    dc.news_hpq0 = table
-    assert torch.equal(with_table, without) and torch.equal(with_table, per_row)
+    dc.news_hpq0, dc.user_hpq0, dc.topic_hpq0 = saved
+    assert torch.equal(with_tables, without) and torch.equal(news_only, without) and torch.equal(with_tables, per_row)
