@@ -158,5 +158,6 @@ class Trainer:
 def evaluate_dev(model, dc, labels, batch_size: int):
     """Per-epoch dev evaluation (trainer.py:109-120): AUC / MRR / nDCG through the HIP inference path."""
     net = model.module if hasattr(model, "module") else model
+    dc.c_n0 = None          # the per-news caches (c_n0, layer-0 projection tables) belong to the weights of the previous epoch
     scores, metrics = util.compute_scores(net, dc, batch_size, labels=labels)
     return AvgMetric(*metrics)
