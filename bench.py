@@ -236,7 +236,7 @@ def main():
     # HBM traffic of the roofline kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass); their per-launch means are kept under profiles/ and quoted here.
     symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(model.graph_encoder, "projection_mode", "").startswith("bf16x6")
-               else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_sparse_kernel" if getattr(model.graph_encoder, "user_xattn_mode", "") == "sparse" else "xattn_score_kernel",
+               else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>", "xattn": "xattn_sparse_kernel" if model.graph_encoder.resolved_xattn_mode("user") == "sparse" else "xattn_score_kernel",
                "agg": "xattn_agg_kernel",
                "topic": "topic_pool_kernel", "pool": "attn_pool_kernel"}
 
@@ -368,8 +368,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["label"], "projection": args.projection,
                    "user_side": "per row" if args.per_row_users else "once per impression (row_group index)",
-                   "user_graph_eq8": getattr(model.graph_encoder, "user_xattn_mode", "dense") + " (chosen from the corpus: mean adjacency entries per node)",
-                   "news_graph_eq8": ("small-graph kernel (n <= 16)" if N <= 16 else getattr(model.graph_encoder, "news_xattn_mode", "dense")),
+                   "user_graph_eq8": model.graph_encoder.resolved_xattn_mode("user") + " (chosen from the corpus: mean adjacency entries per node)",
+                   "news_graph_eq8": ("small-graph kernel (n <= 16)" if N <= 16 else model.graph_encoder.resolved_xattn_mode("news")),
                    "rows_per_step": B, "N": N, "U": H + C, "d": d, "graph_depth": L,
                    "mean_candidates_per_impression": round(mean_cand, 3), "parallelism": f"dp{world} (row shards, no data-path collective)"},
         "rows_per_s": rows_total / elapsed,

@@ -81,6 +81,7 @@ class DIGAT(GraphEncoder):
         # ... and of news graphs of more than 16 nodes: "dense", "sparse" (DIGAT_NEWS_XATTN_SPARSE) or "auto" = dense until
         # util.prepare_news_side has looked at the corpus (there is no device-side decision for this graph)
         self.news_xattn_mode = "auto"
+        self.corpus_xattn_hint = {}        # {"user": "sparse" | "dense", "news": ...}: set by util.prepare_news_side
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -105,6 +106,12 @@ class DIGAT(GraphEncoder):
         nn.init.zeros_(self.featureAffine.bias)
         self.userAttention.initialize()
 
+    def resolved_xattn_mode(self, g: str) -> str:
+        """The Eq. 8 variant in force for graph ``g``: the explicit setting, or what ``util.prepare_news_side`` found in the
+        corpus it was last shown while the setting is "auto" (``corpus_xattn_hint``); "auto" otherwise."""
+        mode = getattr(self, f"{g}_xattn_mode", "auto")
+        return self.corpus_xattn_hint.get(g, "auto") if mode == "auto" else mode
+
     # ------------------------------------------------------------------ parameter block for the C ABI
     def _apply(self, fn, *args, **kwargs):
         self._param_block = None          # .cuda() / .to() move the storages
@@ -120,8 +127,9 @@ class DIGAT(GraphEncoder):
                                          "(call model.cuda()); there is no CPU path")
         P = _lib.Params()
         P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
-        P.flags = ({"auto": 0, "dense": 1, "sparse": 2}[self.user_xattn_mode] | (4 if self.projection_mode == "bf16x6-pq3" else 0)
-                   | (8 if self.news_xattn_mode == "sparse" else 0))
+        P.flags = ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
+                   | (4 if self.projection_mode == "bf16x6-pq3" else 0)
+                   | (8 if self.resolved_xattn_mode("news") == "sparse" else 0))
         P.topic_node_embedding = self.topic_node_embedding.data_ptr()
         P.cand_K = self.candidate_attention.K.weight.data_ptr()
         P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
@@ -182,7 +190,7 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.projection_mode, self.user_xattn_mode, self.news_xattn_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.projection_mode, self.resolved_xattn_mode("user"), self.resolved_xattn_mode("news")) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))
@@ -270,7 +278,7 @@ class DIGAT(GraphEncoder):
         ws = _lib.workspace(nbytes, dev, "xattn")
         W = getattr(self, f"{g}_graph_attention_W")[index]
         F3 = getattr(self, f"{g}_graph_attention_ffn3")[index]
-        mode = getattr(self, f"{g}_xattn_mode", "dense")
+        mode = self.resolved_xattn_mode(g)
         if mode == "sparse" and not return_alpha and n > 16 and d <= 1024:      # the caller knows the graphs are sparse
             _lib.check(L.digat_xattn_fwd_mode(X.data_ptr(), adj.data_ptr(), ctx.data_ptr(), W.weight.data_ptr(), W.bias.data_ptr(),
                                               getattr(self, f"{g}_graph_attention_ffn1")[index].weight.data_ptr(),
@@ -484,8 +492,10 @@ class _Ablation(GraphEncoder):
     compute_news_graph_context = DIGAT.compute_news_graph_context
     compute_user_graph_context = DIGAT.compute_user_graph_context
     _xattn = DIGAT._xattn
+    resolved_xattn_mode = DIGAT.resolved_xattn_mode
     user_xattn_mode = "auto"      # Eq. 8 variant per graph for digat_xattn_fwd_mode ("auto" = dense until
     news_xattn_mode = "auto"      # util.prepare_news_side has looked at the corpus)
+    corpus_xattn_hint: dict = {}  # replaced per instance by util.prepare_news_side
 
     def _gat(self, g: str, index: int, X, A):
         """Vanilla GAT update layer (graphEncoders.py:493-519)."""

@@ -127,14 +127,17 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
             dc.topic_hpq0 = encoder.project_user_layer0(encoder.topic_node_embedding.detach())
     # Eq. 8 of the user graph: the corpus is known here, so the sparse / dense choice the library would otherwise make on
     # the device per batch (both variants launched, one returning at once) is made once, on the host, from the mean
-    # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" is left alone.
-    if getattr(encoder, "user_xattn_mode", None) == "auto" and dc.user_graph.numel() > 0:
-        U = dc.user_graph.shape[1]
-        per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
-        encoder.user_xattn_mode = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
-    if getattr(encoder, "news_xattn_mode", None) == "auto" and N > 16 and dc.news_graph.numel() > 0:
-        per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
-        encoder.news_xattn_mode = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+    # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" setting wins.
+    if hasattr(encoder, "resolved_xattn_mode"):
+        hint = {}
+        if dc.user_graph.numel() > 0:
+            U = dc.user_graph.shape[1]
+            per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
+            hint["user"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+        if N > 16 and dc.news_graph.numel() > 0:
+            per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
+            hint["news"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+        encoder.corpus_xattn_hint = hint          # in force while the encoder's own setting is "auto"
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
