@@ -658,3 +658,30 @@ def test_cached_news_projections_reproduce_the_in_batch_bits():
     per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
     dc.news_hpq0, dc.user_hpq0, dc.topic_hpq0 = saved
     assert torch.equal(with_tables, without) and torch.equal(news_only, without) and torch.equal(with_tables, per_row)
+
+
+@pytest.mark.parametrize("mode", ["auto", "dense", "sparse"])
+def test_layer0_tables_with_every_eq8_variant(mode):
+    """The per-news layer-0 tables feed whichever Eq. 8 variant runs (the dense pair expands the groups' P, the sparse kernel
+    reads through the group index, "auto" launches both): same bits as the per-row path without tables, per variant."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=800, sag_neighbors=3, sag_hops=2, impressions=50, mean_candidates=30.0,
+                               max_candidates=80, seed=95)
+    corpus = synthetic.make_corpus(spec)
+    L = 2
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=96, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 512)
+    model.graph_encoder.user_xattn_mode = mode
+    if mode == "auto":
+        model.graph_encoder.corpus_xattn_hint = {}          # really "auto": the device decides per batch
+    with_tables = util.score_rows(model, dc, 0, dc.rows, 512)
+    per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
+    assert torch.isfinite(with_tables).all() and torch.equal(with_tables, per_row)
