@@ -876,13 +876,12 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
     uint8_t* Au = (uint8_t*)workspace + base;
     uint8_t* cm = Au + align_up((size_t)B * U * U, 256);
     uint8_t* ci = cm + align_up((size_t)B * (C + 1), 256);
-    struct { const uint8_t* in; uint8_t* out; long bytes; } jobs[3] = {
-        {Au_g, Au, (long)U * U}, {cat_mask_g, cm, (long)(C + 1)}, {(const uint8_t*)cat_idx_g, ci, (long)H * 8}};
-    for (auto& j : jobs) {
-        const long total = (long)B * j.bytes;
+    {
+        const GatherJobs jobs{{Au_g, cat_mask_g, (const uint8_t*)cat_idx_g}, {Au, cm, ci}, {(long)U * U, (long)(C + 1), (long)H * 8}};
+        const long total = (long)B * U * U;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, j.in, j.out, row_group, (long)B, j.bytes);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, jobs, row_group, (long)B);
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
