@@ -34,6 +34,8 @@ class Config:
         p.add_argument('--lr', type=float, default=1e-4)
         p.add_argument('--weight_decay', type=float, default=0)
         p.add_argument('--gradient_clip_norm', type=float, default=1)
+        p.add_argument('--early_stopping_epoch', type=int, default=5)
+        p.add_argument('--dev_criterion', default='avg', choices=['auc', 'mrr', 'ndcg5', 'ndcg10', 'avg'])
         p.add_argument('--dropout_rate', type=float, default=0.2)
         p.add_argument('--graph_depth', type=int, default=3)
         p.add_argument('--SAG_hops', type=int, default=2)

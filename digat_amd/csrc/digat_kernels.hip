@@ -180,7 +180,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
         const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
                             sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
-                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr};
+                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr};
         const int rcs = launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
         skip_if = sparse_flag;
@@ -644,7 +644,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                     // Xu[0] was never written: the rows of dead nodes, which layer 1 will not write there and
                                     // the topic pooling after it reads (weight 0, but 0 * NaN = NaN), get X_i now
                                     (xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
-                                    nullptr, nullptr};
+                                    nullptr, nullptr, G, nullptr};
                 rc = launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {

@@ -120,6 +120,9 @@ class DIGAT(GraphEncoder):
     def _params(self) -> "_lib.Params":
         ptrs = tuple(p.data_ptr() for p in self.parameters())
         if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
+            # the Eq. 8 variant only selects kernels (P.flags): it never invalidates the split weights or the folded
+            # queries, so changing it (util.prepare_news_side's corpus hint) must not rebuild them
+            self._param_block[1].flags = self._flags()
             return self._param_block[1]
         for p in self.parameters():
             if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
@@ -127,9 +130,7 @@ class DIGAT(GraphEncoder):
                                          "(call model.cuda()); there is no CPU path")
         P = _lib.Params()
         P.d, P.depth, P.category_num = self.news_embedding_dim, self.graph_depth, self.category_num - 1
-        P.flags = ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
-                   | (4 if self.projection_mode == "bf16x6-pq3" else 0)
-                   | (8 if self.resolved_xattn_mode("news") == "sparse" else 0))
+        P.flags = self._flags()
         P.topic_node_embedding = self.topic_node_embedding.data_ptr()
         P.cand_K = self.candidate_attention.K.weight.data_ptr()
         P.cand_Q = self.candidate_attention.Q.weight.data_ptr()
@@ -184,13 +185,20 @@ class DIGAT(GraphEncoder):
         self._param_block = (ptrs, P, self._fold_key())
         return P
 
+    def _flags(self) -> int:
+        """digat_params.flags (include/digat_hip.h): Eq. 8 variant of the user graph (bits 0-1), DIGAT_PROJ_PQ_X3 (bit 2),
+        DIGAT_NEWS_XATTN_SPARSE (bit 3)."""
+        return ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
+                | (4 if self.projection_mode == "bf16x6-pq3" else 0)
+                | (8 if self.resolved_xattn_mode("news") == "sparse" else 0))
+
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention
         return ((ca.K.weight, ca.Q.weight, ca.Q.bias), (self.user_news_K.weight, self.user_news_Q.weight,
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.projection_mode, self.resolved_xattn_mode("user"), self.resolved_xattn_mode("news")) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.projection_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))

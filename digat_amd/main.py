@@ -32,14 +32,17 @@ def main(argv=None):
     dc = util.DeviceCorpus.from_numpy(corpus, dev)
     if config.mode == 'train':
         trainer = Trainer(model, config, dc, SyntheticTrainSet(corpus, config.negative_sample_num, config.seed),
-                          local_rank=config.local_rank)
+                          local_rank=config.local_rank, dev_labels=corpus.row_label)
         trainer.train(max_steps=config.max_steps or None, log_every=50)
+        if config.local_rank != -1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         if not trainer.is_main_rank:
             return
     if config.local_rank in (-1, 0):
         start = time.time()
         dc.news_embedding = model.news_encoder.table.detach()
-        dc.c_n0 = None
         scores, metrics = util.compute_scores(model, dc, config.batch_size * 16, labels=corpus.row_label)
         print('AUC : %.4f\nMRR : %.4f\nnDCG@5 : %.4f\nnDCG@10 : %.4f' % metrics)
         print('Inference time : %.1fs' % (time.time() - start))

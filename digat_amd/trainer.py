@@ -75,7 +75,7 @@ class SyntheticTrainSet:
 
 class Trainer:
     def __init__(self, model: nn.Module, config, dc: "util.DeviceCorpus", train_set: SyntheticTrainSet,
-                 local_rank: int = -1):
+                 local_rank: int = -1, dev_labels: Optional[np.ndarray] = None, model_dir: Optional[str] = None):
         self.local_rank = local_rank
         self.is_main_rank = local_rank in (-1, 0)
         if local_rank == -1:
@@ -90,6 +90,15 @@ class Trainer:
         self.decay_epoch = lr_decay_epoch(self.epochs)
         self.dc, self.train_set = dc, train_set
         self.losses = []
+        # per-epoch dev evaluation and model selection on the main rank (trainer.py:52-69, :109-172)
+        self.dev_labels = dev_labels
+        self.dev_criterion = getattr(config, "dev_criterion", "avg")
+        self.early_stopping_epoch = getattr(config, "early_stopping_epoch", 5)
+        self.model_dir = model_dir
+        self.auc, self.mrr, self.ndcg5, self.ndcg10 = [], [], [], []
+        self.best_dev_epoch, self.best_dev = 0, None
+        self.epoch_not_increase = 0
+        self.best_state = None
 
     def lr_decay(self):
         for group in self.optimizer.param_groups:
@@ -131,8 +140,38 @@ class Trainer:
         self.optimizer.step()
         return float(loss.item())
 
+    def _criterion(self, metrics):
+        """trainer.py:121-165: the value the best epoch is chosen by (``>=`` keeps the later of two equal epochs)."""
+        auc, mrr, ndcg5, ndcg10 = metrics
+        return {"auc": auc, "mrr": mrr, "ndcg5": ndcg5, "ndcg10": ndcg10}.get(self.dev_criterion, AvgMetric(*metrics))
+
+    def dev_epoch(self, e: int) -> bool:
+        """Main rank, end of epoch e (trainer.py:109-172): score the dev rows through the HIP inference path, track the best
+        epoch, keep / save its state dict.  Returns True when early stopping says stop."""
+        net = self.model.module if hasattr(self.model, "module") else self.model
+        was_training = net.training
+        metrics = evaluate_dev(net, self.dc, self.dev_labels, self.batch_size * 16, as_tuple=True)
+        net.train(was_training)
+        for acc, v in zip((self.auc, self.mrr, self.ndcg5, self.ndcg10), metrics):
+            acc.append(v)
+        print('Epoch %d : dev done\nDev criterions' % e)
+        print('AUC = {:.4f}\nMRR = {:.4f}\nnDCG@5  = {:.4f}\nnDCG@10 = {:.4f}'.format(*metrics), flush=True)
+        value = self._criterion(metrics)
+        if self.best_dev is None or value >= self.best_dev:
+            self.best_dev, self.best_dev_epoch, self.epoch_not_increase = value, e, 0
+            self.best_state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            if self.model_dir is not None:                               # trainer.py:169-170
+                import os
+                os.makedirs(self.model_dir, exist_ok=True)
+                torch.save({net.model_name: net.state_dict()}, os.path.join(self.model_dir, f"{net.model_name}-{e}"))
+        else:
+            self.epoch_not_increase += 1
+        print('Best epoch :', self.best_dev_epoch, flush=True)
+        return self.epoch_not_increase > self.early_stopping_epoch
+
     def train(self, max_steps: Optional[int] = None, log_every: int = 0):
         step = 0
+        distributed = self.local_rank != -1
         for e in range(1, self.epochs + 1):
             self.train_set.negative_sampling()
             if e == self.decay_epoch:
@@ -147,17 +186,36 @@ class Trainer:
                 if log_every and self.is_main_rank and step % log_every == 0:
                     print(f"epoch {e} step {step} loss {loss:.4f}", flush=True)
                 if max_steps is not None and step >= max_steps:
-                    self.losses.append(epoch_loss / max(nb, 1))
-                    return self.losses
+                    break
             self.losses.append(epoch_loss / max(nb, 1))
             if self.is_main_rank:
                 print(f"Epoch {e} : train done\nloss = {self.losses[-1]}", flush=True)
+            stop = max_steps is not None and step >= max_steps
+            if self.dev_labels is not None and self.is_main_rank:
+                stop = self.dev_epoch(e) or stop
+            if distributed:
+                # the reference breaks out on the main rank only (trainer.py:171-172) and leaves the others waiting in the next
+                # all-reduce until the 12 h timeout; here the decision is broadcast
+                import torch.distributed as dist
+                flag = torch.tensor([int(stop)], device=self.dc.news_embedding.device)
+                dist.broadcast(flag, src=0)
+                stop = bool(flag.item())
+            if stop:
+                break
+        if self.is_main_rank and self.best_state is not None:           # trainer.py:188: the best epoch's weights are the result
+            net = self.model.module if hasattr(self.model, "module") else self.model
+            net.load_state_dict(self.best_state)
+            if self.model_dir is not None:
+                import os
+                torch.save({net.model_name: net.state_dict()}, os.path.join(self.model_dir, net.model_name))
         return self.losses
 
 
-def evaluate_dev(model, dc, labels, batch_size: int):
-    """Per-epoch dev evaluation (trainer.py:109-120): AUC / MRR / nDCG through the HIP inference path."""
+def evaluate_dev(model, dc, labels, batch_size: int, as_tuple: bool = False):
+    """Per-epoch dev evaluation (trainer.py:109-120): AUC / MRR / nDCG through the HIP inference path.  The per-news caches
+    (c_n0, layer-0 projection tables) are recomputed when the weights have moved on (``util.weights_key``)."""
     net = model.module if hasattr(model, "module") else model
-    dc.c_n0 = None          # the per-news caches (c_n0, layer-0 projection tables) belong to the weights of the previous epoch
+    if hasattr(net.news_encoder, "table"):
+        dc.news_embedding = net.news_encoder.table.detach()             # a trainable table is the news-representation cache
     scores, metrics = util.compute_scores(net, dc, batch_size, labels=labels)
-    return AvgMetric(*metrics)
+    return tuple(metrics) if as_tuple else AvgMetric(*metrics)

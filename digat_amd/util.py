@@ -44,6 +44,7 @@ class DeviceCorpus:
     news_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, N, d]: layer 0's [h|P|Q] of every news graph
     user_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, d]: layer 0's user-graph [h|P|Q] of every news as a history node
     topic_hpq0: Optional[torch.Tensor] = None                # [3, C, d]: ... of the topic nodes
+    weights_key: Optional[tuple] = None                      # the weight version the five caches above were computed from
 
     @classmethod
     def from_numpy(cls, corpus, device) -> "DeviceCorpus":
@@ -101,6 +102,19 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
     """util.py:34-44: gather the SA neighbourhood embeddings and precompute c_n0 for every news."""
     news_num, N = dc.news_node_ID.shape
     d = dc.news_embedding.shape[1]
+    # Eq. 8 of the user graph: the corpus is known here, so the sparse / dense choice the library would otherwise make on
+    # the device per batch (both variants launched, one returning at once) is made once, on the host, from the mean
+    # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" setting wins.
+    if hasattr(encoder, "resolved_xattn_mode"):
+        hint = {}
+        if dc.user_graph.numel() > 0:
+            U = dc.user_graph.shape[1]
+            per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
+            hint["user"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+        if N > 16 and dc.news_graph.numel() > 0:
+            per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
+            hint["news"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
+        encoder.corpus_xattn_hint = hint          # in force while the encoder's own setting is "auto"
     dc.SA_news_representations = dc.news_embedding.index_select(0, dc.news_node_ID.flatten()).view(news_num, N, d)
     c_n0 = torch.empty((news_num, d), dtype=torch.float32, device=dc.news_embedding.device)
     with torch.no_grad():
@@ -125,19 +139,14 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
         with torch.no_grad():
             dc.user_hpq0 = encoder.project_user_layer0(dc.news_embedding)
             dc.topic_hpq0 = encoder.project_user_layer0(encoder.topic_node_embedding.detach())
-    # Eq. 8 of the user graph: the corpus is known here, so the sparse / dense choice the library would otherwise make on
-    # the device per batch (both variants launched, one returning at once) is made once, on the host, from the mean
-    # number of adjacency entries per node (MIND user graphs: ~4 of 67).  An explicit "dense" / "sparse" setting wins.
-    if hasattr(encoder, "resolved_xattn_mode"):
-        hint = {}
-        if dc.user_graph.numel() > 0:
-            U = dc.user_graph.shape[1]
-            per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * U))
-            hint["user"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
-        if N > 16 and dc.news_graph.numel() > 0:
-            per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
-            hint["news"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
-        encoder.corpus_xattn_hint = hint          # in force while the encoder's own setting is "auto"
+    dc.weights_key = weights_key(encoder, dc)
+
+
+def weights_key(encoder, dc: DeviceCorpus) -> tuple:
+    """What the per-news caches of ``prepare_news_side`` depend on: every encoder parameter's storage and version counter
+    (an optimizer step or ``load_state_dict`` bumps them) and the news representations they were computed from."""
+    params = tuple((p.data_ptr(), p._version) for p in encoder.parameters()) if hasattr(encoder, "parameters") else ()
+    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, getattr(encoder, "projection_mode", None))
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
@@ -314,6 +323,12 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     lanes = batch_streams(dev, max(1, streams))
     with torch.no_grad():
         pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy()) if grouped and batches else None
+        # the parameter block (split weights, folded queries) is (re)built on the first lane BEFORE the other lanes are
+        # ordered after it: a rebuild inside the loop would run on one lane while the next batch reads it on the other
+        enc = getattr(model, "graph_encoder", None)
+        if enc is not None and hasattr(enc, "_params") and batches:
+            with torch.cuda.stream(lanes[0]):
+                enc._params()
         for extra in lanes[1:]:
             extra.wait_stream(lanes[0])                       # the corpus tables, `scores`, the pipeline's index arrays
         for k, (s, e) in enumerate(batches):
@@ -354,8 +369,9 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
     ``score_fn(model, dc, start, end, batch_size)`` replaces the scorer (tests)."""
     if hasattr(model, "eval"):
         model.eval()
-    if dc.c_n0 is None and score_fn is None:
-        prepare_news_side(model.graph_encoder, dc, batch_size)
+    if score_fn is None and (dc.c_n0 is None or dc.weights_key != weights_key(model.graph_encoder, dc)):
+        prepare_news_side(model.graph_encoder, dc, batch_size)      # first use, or the weights moved on since (an optimizer
+                                                                    # step, load_state_dict): the per-news caches are stale
     row_imp = dc.row_impression.cpu().numpy()
     start, end = shard_rows(row_imp, world_size, rank)
     local = (score_fn or score_rows)(model, dc, start, end, batch_size)

@@ -16,7 +16,7 @@ Three modules the reference imports are not installable here (no network) and ar
     pins this boundary, so this stub *defines* it; the oracle's vectorised version is
     cross-checked against the same naive loop in tests/.
 
-Usage:  python oracle/make_golden.py            (rewrites every fixture, deterministic)
+Usage:  python oracle/make_golden.py [name ...]   (no names: rewrites every fixture; deterministic)
 """
 from __future__ import annotations
 
@@ -291,6 +291,89 @@ def fixture_train_step(ge):
          g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
 
 
+def grad_digest(name, g):
+    """Compact, order-sensitive digest of one gradient tensor: its L2 norm, its dot product with a fixed pseudo-random
+    probe (seeded by the parameter name), and every ``stride``-th element.  21 MB of production-shape gradients would not
+    belong in the repository; a wrong element almost surely moves the probe, a wrong scale moves the norm, and the
+    samples localise a failure."""
+    flat = np.asarray(g, dtype=np.float32).reshape(-1)
+    seed = int.from_bytes(name.encode()[-8:].rjust(8, b"\0"), "little") % (2 ** 32)
+    probe = np.random.default_rng(seed).standard_normal(flat.size).astype(np.float32)
+    stride = max(1, flat.size // 2048)
+    return {"gn_" + name: np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum())),
+            "gp_" + name: np.float64((flat.astype(np.float64) * probe).sum()),
+            "gs_" + name: flat[::stride].copy()}
+
+
+def fixture_train_step_default(ge):
+    """(v-b) one training step at the PRODUCTION shapes (MIND-small default: N=10, U=67, d=400, L=3; B=8 impressions x
+    K=5 candidates = 40 rows -> 2 680 user-node rows, so the >= 2048-row GEMM paths are taken), dropout 0, from the
+    reference's autograd.  Inputs and weights regenerate from seeds; logits, loss and the two input gradients are stored
+    whole, parameter gradients as digests (``grad_digest``)."""
+    B, K, N, H, C, d, L = 8, 5, 10, 50, 17, 400, 3
+    seeds = (91, 92, 93)
+    state = synthetic.make_state_dict(d, C, L, seed=seeds[0], bias_std=0.05)
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=seeds[1])
+    users = synthetic.make_encoder_batch(B, N, H, C, d, seed=seeds[2], empty_history_rows=(3,))
+    enc = reference_encoder(ge, N, H, C, d, L, state, dropout=0.0).train()
+    Xn = T(flat["news_graph_embeddings"]).requires_grad_(True)
+    ue = T(users["user_news_embedding"]).requires_grad_(True)
+
+    def expand(t):                                                          # model.py:64-71
+        return t.unsqueeze(1).expand(B, K, *t.shape[1:]).contiguous().view(B * K, *t.shape[1:])
+
+    n, u = enc(Xn, T(flat["news_graph"]), T(flat["news_graph_mask"]), expand(ue),
+               expand(T(users["user_graph"])), expand(T(users["user_category_mask"])),
+               expand(T(users["user_category_indices"])))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+    loss.backward()
+    digests = {}
+    for k, v in enc.named_parameters():
+        digests.update(grad_digest(k, v.grad.numpy()))
+    both = dict(flat)
+    both.update({"u_" + k: v for k, v in users.items()})
+    save("train_step_default.npz", meta=np.array([B, K, N, H, C, d, L]), seeds=np.array(seeds),
+         input_checksum=checksum(both, state),
+         out_logits=logits.detach().numpy(), out_loss=loss.detach().numpy(),
+         out_news_ctx=n.detach().numpy(), out_user_ctx=u.detach().numpy(),
+         g_in_news_graph_embeddings=Xn.grad.numpy(),
+         g_in_user_news_embedding=ue.grad.numpy(), **digests)
+
+
+def fixture_devset_2k(ge, ev):
+    """(iv-b) a 2 000-impression dev set at the MIND-small default shapes (d=400, N=10, U=67, L=3, ~37 candidates per
+    impression: ~74 k rows), scored by the reference encoder (about ten minutes of CPU in the build container), ranked by
+    util.py:70-80's rule, metrics by evaluate.scoring.  Large enough that near-ties between candidates occur."""
+    spec = synthetic.SynthSpec(news_num=4096, sag_neighbors=3, sag_hops=2, impressions=2000, seed=47)
+    L = 3
+    corpus = synthetic.make_corpus(spec)
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=spec.seed + 1, bias_std=0.05)
+    enc = reference_encoder(ge, spec.news_graph_size, spec.max_history_num, spec.category_num, spec.embedding_dim, L, state)
+    scores, c_n0 = reference_scores(enc, corpus, 128)
+    sub = [[] for _ in range(int(corpus.row_impression[-1]) + 1)]
+    labels = [[] for _ in sub]
+    for i, imp in enumerate(corpus.row_impression.tolist()):
+        sub[imp].append([float(scores[i]), len(sub[imp])])
+        labels[imp].append(int(corpus.row_label[i]))
+    lines, truth = [], []
+    for i, s in enumerate(sub):                                             # util.py:70-80
+        s.sort(key=lambda x: x[0], reverse=True)
+        res = [0] * len(s)
+        for j in range(len(s)):
+            res[s[j][1]] = j + 1
+        lines.append(str(i + 1) + " " + str(res).replace(" ", ""))
+        truth.append(str(i + 1) + " " + str(labels[i]).replace(" ", ""))
+    auc, mrr, n5, n10 = ev.scoring(io.StringIO("\n".join(truth)), io.StringIO("\n".join(lines)))
+    print(f"  devset_2k: rows={corpus.rows} AUC={auc:.6f} MRR={mrr:.6f} nDCG5={n5:.6f} nDCG10={n10:.6f}")
+    ranks = np.concatenate([np.array(eval(l.split(" ", 1)[1]), dtype=np.int16) for l in lines])   # our own output lines
+    save("devset_2k.npz", depth=np.array(L), scores=scores.astype(np.float32), ranks=ranks,
+         c_n0_head=c_n0[:64].astype(np.float32), metrics=np.array([auc, mrr, n5, n10], dtype=np.float64),
+         input_checksum=np.float64(float(corpus.news_embedding.astype(np.float64).sum())
+                                   + float(corpus.user_graph.sum()) + float(corpus.news_graph.sum())
+                                   + float(corpus.row_candidate.astype(np.float64).sum())))
+
+
 def fixture_ablations(ge):
     """the five ablation encoders (graphEncoders.py:201-842), eval-mode forward and inference, at the tiny
     shapes (inputs stored) and at the default shapes (inputs and weights regenerate from seeds).  Loading the
@@ -404,14 +487,13 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     ge, ev = import_reference()
     print("reference imported from", REFERENCE)
-    fixture_tiny(ge)
-    fixture_edges(ge)
-    fixture_train_step(ge)
-    fixture_devset(ge, ev)
-    fixture_default(ge)
-    fixture_ablations(ge)
-    fixture_msa()
-    fixture_sag()
+    jobs = {"tiny": lambda: fixture_tiny(ge), "edges": lambda: fixture_edges(ge), "train_step": lambda: fixture_train_step(ge),
+            "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev),
+            "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge), "msa": fixture_msa,
+            "sag": fixture_sag, "devset_2k": lambda: fixture_devset_2k(ge, ev)}
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]        # python oracle/make_golden.py [name ...]
+    for name in (only or list(jobs)):
+        jobs[name]()
 
 
 if __name__ == "__main__":

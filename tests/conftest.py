@@ -42,6 +42,49 @@ def regenerate(fx):
     return batch, state
 
 
+def grad_digest(name, g):
+    """The digest oracle/make_golden.py stores for a production-shape gradient: (L2 norm, dot product with a fixed
+    pseudo-random probe seeded by the parameter name, every stride-th element)."""
+    flat = np.asarray(g, dtype=np.float32).reshape(-1)
+    seed = int.from_bytes(name.encode()[-8:].rjust(8, b"\0"), "little") % (2 ** 32)
+    probe = np.random.default_rng(seed).standard_normal(flat.size).astype(np.float32)
+    stride = max(1, flat.size // 2048)
+    return (float(np.sqrt((flat.astype(np.float64) ** 2).sum())), float((flat.astype(np.float64) * probe).sum()),
+            flat[::stride].copy())
+
+
+def check_grad_digest(fx, name, g, rtol, what=""):
+    """Hold gradient ``g`` of parameter ``name`` to the digest in fixture ``fx``; tolerances relative to the gradient's norm."""
+    norm, dot, samples = grad_digest(name, g)
+    want_norm, want_dot, want_samples = float(fx["gn_" + name]), float(fx["gp_" + name]), fx["gs_" + name]
+    scale = max(want_norm, 1e-30)
+    assert abs(norm - want_norm) <= rtol * scale, f"{what}{name}: |g| = {norm:.6e}, reference {want_norm:.6e}"
+    # the probe is a unit-variance random vector: |<g - g_ref, probe>| ~ |g - g_ref|
+    assert abs(dot - want_dot) <= 4 * rtol * scale, f"{what}{name}: probe {dot:.6e}, reference {want_dot:.6e} (|g| {want_norm:.3e})"
+    n = max(1, np.asarray(g).size)
+    tol = rtol * scale / np.sqrt(n) * 30 + rtol * np.abs(want_samples)          # elementwise: 30 x the rms budget + relative
+    bad = np.abs(samples - want_samples) > tol
+    assert not bad.any(), f"{what}{name}: {int(bad.sum())} of {len(samples)} sampled elements off, worst {np.abs(samples - want_samples).max():.3e}"
+
+
+def regenerate_train(fx):
+    """Inputs and weights of train_step_default.npz: (meta, state, per-row news batch, per-impression user batch)."""
+    from digat_amd import synthetic
+    B, K, N, H, C, d, L = (int(v) for v in fx["meta"])
+    s_w, s_n, s_u = (int(v) for v in fx["seeds"])
+    state = synthetic.make_state_dict(d, C, L, seed=s_w, bias_std=0.05)
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=s_n)
+    users = synthetic.make_encoder_batch(B, N, H, C, d, seed=s_u, empty_history_rows=(3,))
+    both = dict(flat)
+    both.update({"u_" + k: v for k, v in users.items()})
+    tot = 0.0
+    for v in list(both.values()) + list(state.values()):
+        tot += float(np.asarray(v, dtype=np.float64).sum())
+    assert abs(tot - float(fx["input_checksum"])) <= 1e-6 * max(1.0, abs(tot)), \
+        "synthetic generator drifted from the one that minted the fixture"
+    return (B, K, N, H, C, d, L), state, flat, users
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

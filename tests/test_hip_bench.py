@@ -21,8 +21,8 @@ def _last_json_line(out):
 
 
 def test_bench_single_gpu_prints_the_contract_line():
-    cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "256", "--news", "2048",
-           "--cpu-rows", "256", "--cpu-seconds", "5"]
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "600", "--news", "2048",
+           "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2"]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
@@ -33,16 +33,39 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and 0 < roof["frac"] < 1
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
-    assert line["auc_match"]["max_abs_metric_diff"] <= line["auc_match"]["tolerance"]
+    assert line["auc_match"]["max_abs_metric_diff"] <= line["auc_match"]["tolerance"] and line["valid"] is True
+    assert "AUC-matched" in line["metric"]
+    rx = line["roofline_xattn"]
+    assert rx["bound"] == "hbm" and 0 < rx["frac"] < 1
+    assert line["setup_ms"] > 0 and line["config"]["news_num"] == 2048
+    ex = line["extra_workloads"]
+    assert set(ex) == {"mind-small-stress", "mind-large-default"} and all(v["value"] > 0 for v in ex.values())
+    assert ex["mind-small-stress"]["config"]["N"] == 65 and ex["mind-large-default"]["config"]["N"] == 26
 
 
 def test_bench_two_ranks_sum_their_rows():
     env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "256", "--news", "2048"]
+           "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "600", "--news", "2048"]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert REQUIRED <= set(line)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None       # rank 0 at N=1 only
+    assert line["config"]["N"] == 26 and "MIND-large" in line["config"]["workload"]     # BASELINE configs[3]'s shape at N > 1
+    assert line["auc_match"]["max_abs_metric_diff"] <= 1e-4
+
+
+def test_bench_train_mode_two_ranks_ddp():
+    """--mode train under torch.distributed.run: DistributedDataParallel around Model.forward / the HIP backward."""
+    env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", "bench.py", "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1",
+           "--impressions", "400", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    assert line["n_gpus"] == 2 and line["unit"] == "rows/s" and line["value"] > 0 and "ddp2" in line["config"]["parallelism"]
+    import math
+    assert math.isfinite(line["final_loss"])

@@ -685,3 +685,115 @@ def test_layer0_tables_with_every_eq8_variant(mode):
     with_tables = util.score_rows(model, dc, 0, dc.rows, 512)
     per_row = util.score_rows(model, dc, 0, dc.rows, 512, grouped=False)
     assert torch.isfinite(with_tables).all() and torch.equal(with_tables, per_row)
+
+
+# --------------------------------------------------------------------------------------------------
+# a6 / a7 on their own: ScaledDotProductAttention (layers.py:199-206) and torch_scatter's scatter_softmax + scatter_sum
+# (graphEncoders.py:129-130) through their own C-ABI entries, not through a3 / a4
+# --------------------------------------------------------------------------------------------------
+def _folded_query(query, Kw, Qw, bQ):
+    """kq = K^T (Q query + b) through the C ABI (digat_linear_f32, digat_linear_bwd_input): (K x).(Q q + b) = x.kq."""
+    from digat_amd import _lib
+    L = _lib.lib()
+    B, d = query.shape
+    qv = torch.empty((B, d), device=_dev())
+    kq = torch.empty((B, d), device=_dev())
+    _lib.check(L.digat_linear_f32(query.data_ptr(), query.stride(0), Qw.data_ptr(), bQ.data_ptr(), qv.data_ptr(), d, B, d, d,
+                                  _lib.stream_ptr()), "digat_linear_f32")
+    _lib.check(L.digat_linear_bwd_input(qv.data_ptr(), d, Kw.data_ptr(), kq.data_ptr(), d, B, d, d, 0, _lib.stream_ptr()),
+               "digat_linear_bwd_input")
+    return kq
+
+
+@pytest.mark.parametrize("name", ["tiny.npz", "edges.npz", "default_b8.npz", "stress_b2.npz"])
+def test_a6_scaled_dot_product_attention_standalone(name):
+    """digat_attn_pool_fwd against the reference-minted ``a6_sdpa_candidate`` (candidate_attention over the news graph's
+    nodes, query = node 0; edges.npz holds fully masked rows: uniform attention over every node, E1)."""
+    from digat_amd import _lib
+    fx = load_golden(name)
+    if "in_news_graph_embeddings" in fx:
+        ins, w, outs = split_fixture(fx)
+        want = outs["a6_sdpa_candidate"]
+    else:
+        ins, w = regenerate(fx)
+        want = fx["out_a6_sdpa_candidate"]
+    X = torch.from_numpy(np.ascontiguousarray(ins["news_graph_embeddings"])).to(_dev())
+    mask = torch.from_numpy(np.ascontiguousarray(ins["news_graph_mask"])).to(_dev()).view(torch.uint8)
+    B, N, d = X.shape
+    Kw, Qw, bQ = (torch.from_numpy(np.ascontiguousarray(w[f"candidate_attention.{k}"])).to(_dev())
+                  for k in ("K.weight", "Q.weight", "Q.bias"))
+    kq = _folded_query(X[:, 0], Kw, Qw, bQ)
+    out = torch.full((B, d), float("nan"), device=_dev())
+    alpha = torch.full((B, N), float("nan"), device=_dev())
+    _lib.check(_lib.lib().digat_attn_pool_fwd(X.data_ptr(), N * d, kq.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                              alpha.data_ptr(), B, N, d, _lib.stream_ptr()), "digat_attn_pool_fwd")
+    torch.cuda.synchronize()
+    close(out, want, f"{name}: a6_sdpa_candidate")
+    a = alpha.cpu().numpy()
+    np.testing.assert_allclose(a.sum(axis=1), 1.0, rtol=0, atol=2e-6)
+    m = np.asarray(ins["news_graph_mask"]).astype(bool)
+    some = m.any(axis=1)
+    assert (a[some][~m[some]] == 0).all()                           # exp(-1e9 - max) is exactly 0 in fp32
+    if (~some).any():
+        np.testing.assert_allclose(a[~some], 1.0 / N, rtol=1e-6)    # all -1e9: uniform
+
+
+def _topic_case(B, H, C, d, seed, kind):
+    rng = np.random.default_rng(seed)
+    C1 = C + 1
+    idx = rng.integers(0, C, size=(B, H)).astype(np.int64)
+    if kind == "padded":              # MIND-like: a ragged tail of padding slots in bucket C
+        ln = rng.integers(0, H + 1, size=B)
+        ln[0], ln[-1] = 0, H          # one user without history (everything in bucket C), one full
+        idx[np.arange(H)[None, :] >= ln[:, None]] = C
+    elif kind == "all_in_C":
+        idx[:] = C
+    elif kind == "single":            # every history item in one category: one segment of H, the rest empty
+        idx[:] = rng.integers(0, C, size=(B, 1))
+    elif kind == "sorted":            # long runs
+        idx = np.sort(idx, axis=1)
+    U = H + C
+    Xu = (0.5 * rng.standard_normal((B, U, d))).astype(np.float32)
+    c_n = (0.7 * rng.standard_normal((B, d))).astype(np.float32)
+    return Xu, idx, c_n, C1
+
+
+@pytest.mark.parametrize("B,H,C,d,kind", [(16, 50, 17, 400, "padded"), (8, 50, 17, 400, "all_in_C"), (8, 50, 17, 400, "single"),
+                                          (5, 10, 5, 64, "padded"), (6, 64, 17, 400, "sorted"), (6, 80, 9, 128, "padded"),
+                                          (4, 200, 30, 64, "single"), (3, 1, 3, 32, "padded")])
+def test_a7_topic_pooling_standalone(B, H, C, d, kind):
+    """digat_topic_pool_fwd (H <= 64: the register-resident kernel; beyond: topic_pool_kernel) against the oracle's
+    restatement of scatter_softmax + scatter_sum (graphEncoders.py:126-130) AND against a per-segment Python loop in
+    float64; empty segments must come out exactly zero (scatter_sum's dim_size = C + 1 rows)."""
+    from digat_amd import _lib, synthetic
+    Xu, idx, c_n, C1 = _topic_case(B, H, C, d, seed=B * 1000 + H + C, kind=kind)
+    state = synthetic.make_state_dict(d, C, 1, seed=7, bias_std=0.05)
+    p = O.as_params(state)
+    want = O.topic_pooling(p, torch.from_numpy(Xu), torch.from_numpy(idx), torch.from_numpy(c_n), H).numpy()
+    # float64 loop: a_t = (K x_t).(Q c + b)/sqrt(d); per segment softmax; weighted sum
+    K64, Q64, b64 = (state[f"user_news_{k}"].astype(np.float64) for k in ("K.weight", "Q.weight", "Q.bias"))
+    naive = np.zeros((B, C1, d))
+    for b in range(B):
+        hist = Xu[b, :H].astype(np.float64)
+        a = (hist @ K64.T) @ (Q64 @ c_n[b].astype(np.float64) + b64) / np.sqrt(d)
+        for s in range(C1):
+            sel = np.nonzero(idx[b] == s)[0]
+            if sel.size:
+                e = np.exp(a[sel] - a[sel].max())
+                naive[b, s] = (e / e.sum()) @ hist[sel]
+    np.testing.assert_allclose(want, naive, rtol=1e-4, atol=2e-5)           # the oracle itself vs the definition
+    Xd, id_, cd = (torch.from_numpy(v).to(_dev()) for v in (Xu, idx, c_n))
+    Kw, Qw, bQ = (torch.from_numpy(np.ascontiguousarray(state[f"user_news_{k}"])).to(_dev())
+                  for k in ("K.weight", "Q.weight", "Q.bias"))
+    kq = _folded_query(cd, Kw, Qw, bQ)
+    out = torch.full((B, C1, d), float("nan"), device=_dev())
+    _lib.check(_lib.lib().digat_topic_pool_fwd(Xd.data_ptr(), kq.data_ptr(), id_.data_ptr(), out.data_ptr(), B, H + C, H, C1, d,
+                                               _lib.stream_ptr()), "digat_topic_pool_fwd")
+    torch.cuda.synchronize()
+    close(out, want, f"topic pooling {kind} B={B} H={H} C={C} d={d}")
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, naive, rtol=1e-4, atol=2e-5)
+    empty = np.ones((B, C1), dtype=bool)
+    for b in range(B):
+        empty[b, np.unique(idx[b])] = False
+    assert (got[empty] == 0).all(), "empty segments must be exactly zero"

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_fixture
+from conftest import check_grad_digest, load_golden, regenerate_train, split_fixture
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -70,6 +70,38 @@ def test_training_step_matches_reference_autograd():
     for name, p in enc.named_parameters():
         assert p.grad is not None, name
         close(p.grad, fx["g_" + name], "grad " + name)
+
+
+def build_default(dropout=0.0):
+    """train_step_default.npz: the production shapes (N=10, U=67, d=400, L=3; 40 rows -> 2 680 user-node rows, so the
+    bf16x6 training GEMMs (`_x3_ok`), multi-slice `gemm_tn_kernel` launches and the pairwise backward at n=67 all run)."""
+    from digat_amd.graphEncoders import DIGAT
+    fx = load_golden("train_step_default.npz")
+    dims, w, flat, users = regenerate_train(fx)
+    B, K, N, H, C, d, L = dims
+    cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C, graph_depth=L, dropout_rate=dropout)
+    enc = DIGAT(cfg, d)
+    enc.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()})
+    enc = enc.to(DEV).train()
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in flat.items() if k.startswith("news_")}
+    t.update({k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in users.items() if k.startswith("user_")})
+    return fx, enc, t, dims
+
+
+def test_training_step_at_production_shapes_matches_reference_autograd():
+    from digat_amd import training
+    fx, enc, t, dims = build_default()
+    B, K, N, H, C, d, L = dims
+    assert training._x3_ok(B * K * (H + C), d, d), "the fixture must reach the bf16x6 training GEMMs"
+    logits, loss, Xn, ue = run_step(enc, t, dims)
+    torch.cuda.synchronize()
+    close(logits, fx["out_logits"], "logits", rtol=2e-5, atol=2e-5)
+    close(loss, fx["out_loss"], "loss", rtol=1e-5, atol=1e-6)
+    close(Xn.grad, fx["g_in_news_graph_embeddings"], "d news_graph_embeddings")
+    close(ue.grad, fx["g_in_user_news_embedding"], "d user_news_embedding")
+    for name, p in enc.named_parameters():
+        assert p.grad is not None, name
+        check_grad_digest(fx, name, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
 
 
 def test_training_gradients_are_reproducible():

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, regenerate, split_fixture
+from conftest import check_grad_digest, load_golden, regenerate, regenerate_train, split_fixture
 from oracle import digat_oracle as O
 
 RTOL, ATOL = 1e-5, 1e-5
@@ -222,3 +222,26 @@ def test_ablation_oracle_matches_reference(name, tag):
         inn, inu = O.ablation_encode(name, p, L, *args, c_n=c0)
     for got, key in ((fn, "out_forward_news"), (fu, "out_forward_user"), (inn, "out_inference_news"), (inu, "out_inference_user")):
         np.testing.assert_allclose(got.numpy(), fx[key], rtol=1e-5, atol=ATOL, err_msg=f"{name}/{tag}/{key}")
+
+
+def test_train_step_at_production_shapes():
+    """The oracle's autograd against the reference's at N=10, U=67, d=400, L=3, 40 rows (train_step_default.npz: logits,
+    loss, contexts and input gradients whole, parameter gradients as digests)."""
+    fx = load_golden("train_step_default.npz")
+    (B, K, N, H, C, d, L), w, flat, users = regenerate_train(fx)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.as_params(w).items()}
+    Xn = torch.from_numpy(flat["news_graph_embeddings"]).view(B, K, N, d).clone().requires_grad_(True)
+    ue = torch.from_numpy(users["user_news_embedding"]).clone().requires_grad_(True)
+    logits = O.training_logits(p, L, ue, torch.from_numpy(users["user_graph"]),
+                               torch.from_numpy(users["user_category_mask"]),
+                               torch.from_numpy(users["user_category_indices"]), Xn,
+                               torch.from_numpy(flat["news_graph"]).view(B, K, N, N),
+                               torch.from_numpy(flat["news_graph_mask"]).view(B, K, N))
+    loss = O.training_loss(logits)
+    loss.backward()
+    close(logits.detach().numpy(), fx["out_logits"], "logits")
+    close(loss.detach().numpy(), fx["out_loss"], "loss")
+    close(Xn.grad.view(B * K, N, d).numpy(), fx["g_in_news_graph_embeddings"], "dX_news")
+    close(ue.grad.numpy(), fx["g_in_user_news_embedding"], "dX_user")
+    for k, v in p.items():
+        check_grad_digest(fx, k, v.grad.numpy(), 2e-5, "oracle grad ")

@@ -41,3 +41,38 @@ def test_negative_sampling_and_loss():
     logits = torch.tensor([[2.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
     want = (-torch.log_softmax(logits, dim=1)[:, 0]).mean()
     assert torch.allclose(training_loss(logits), want)
+
+
+def test_per_epoch_dev_selection_and_early_stopping(monkeypatch):
+    """trainer.py:109-172 on the host: the best epoch by the dev criterion (`>=`: the later of two equal epochs), early
+    stopping after `early_stopping_epoch` epochs without improvement, the best epoch's weights restored at the end."""
+    import numpy as np
+    from digat_amd import trainer as T
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=4, max_history_num=10,
+                                category_num=5, graph_depth=1, dropout_rate=0.2, epoch=10, batch_size=4, lr=1e-3,
+                                early_stopping_epoch=2, dev_criterion="auc")
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.zeros(16, 64), trainable=True))
+    spec = synthetic.SynthSpec(news_num=64, sag_neighbors=3, sag_hops=1, max_history_num=10, category_num=5,
+                               embedding_dim=64, impressions=12, mean_candidates=6.0, max_candidates=12, seed=4)
+    corpus = synthetic.make_corpus(spec)
+    dc = types.SimpleNamespace(news_embedding=torch.zeros(1))
+    tr = T.Trainer(model, cfg, dc, T.SyntheticTrainSet(corpus, 4, 0), dev_labels=corpus.row_label)
+    aucs = iter([0.50, 0.60, 0.60, 0.55, 0.58, 0.59, 0.70])           # epochs 1..: best = 3 (>=), stop after epoch 6
+    marks = []
+
+    def fake_step(idx):
+        with torch.no_grad():
+            model.graph_encoder.topic_node_embedding.add_(1.0)          # the weights move every step
+        return 0.0
+
+    def fake_dev(net, dc_, labels, bs, as_tuple=False):
+        marks.append(float(net.graph_encoder.topic_node_embedding[0, 0]))
+        return (next(aucs), 0.3, 0.3, 0.3)
+    monkeypatch.setattr(tr, "train_step", fake_step)
+    monkeypatch.setattr(tr, "batches", lambda e: iter([np.arange(2)]))
+    monkeypatch.setattr(T, "evaluate_dev", fake_dev)
+    tr.train()
+    assert tr.best_dev_epoch == 3 and tr.auc == [0.50, 0.60, 0.60, 0.55, 0.58, 0.59]
+    assert len(tr.losses) == 6                                          # epochs 4, 5, 6 did not improve: 3 > 2 -> stop
+    assert float(model.graph_encoder.topic_node_embedding[0, 0]) == marks[2] == 3.0     # epoch 3's weights are the result
