@@ -21,4 +21,4 @@ def test_ddp_gradients_equal_single_process_gradients_of_the_union():
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert res.returncode == 0 and lines, (res.stdout[-1500:], res.stderr[-2500:])
     out = json.loads(lines[-1])
-    assert out["ok"] and out["world"] == 2 and out["params"] > 50, out
+    assert out["ok"] and out["world"] == 2 and out["params"] >= 40, out
