@@ -111,6 +111,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
 #include "digat_xattn.inc"
 #include "digat_context.inc"
 #include "digat_glue.inc"
+#include "digat_staged.inc"
 
 // =================================================================================================
 // C ABI
@@ -157,7 +158,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
-                      int pq_x3 = 0) {
+                      int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -181,7 +182,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
         const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
                             sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
                             listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr};
-        const int rcs = launch_sparse(sg, st);
+        // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
+        const int rcs = plan ? launch_staged(sg, *plan, listed && live ? 1 : 0, plan_slot, st) : launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
         skip_if = sparse_flag;
     }
@@ -397,6 +399,9 @@ struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
 static int g_sparse_per_node = getenv("DIGAT_SPARSE_PER_NODE") ? atoi(getenv("DIGAT_SPARSE_PER_NODE")) : 12;
 static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
+// 0 (default): the wave-per-centre sparse kernel; 1: the LDS-staged kernels of digat_staged.inc (compulsory HBM traffic, measured
+// slower in round 2: DESIGN.md section 4)
+static int g_staged_on = getenv("DIGAT_XATTN_STAGED") ? atoi(getenv("DIGAT_XATTN_STAGED")) : 0;
 static SideStream* side_stream() {
     static SideStream tab[16];
     static int state[16];                    // 0 = untried, 1 = ready, -1 = unavailable
@@ -418,7 +423,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* c_n, float* c_u, int B, int N, int H, float* const Xu[2], float* const Xn[2],
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
-                              const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0) {
+                              const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
+                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
@@ -471,6 +477,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     const int* sparse_flag = nullptr;
     const int pq_x3 = (p->flags & DIGAT_PROJ_PQ_X3) ? 1 : 0;
     const bool want_scan = want_live || sparse_mode == DIGAT_XATTN_AUTO;      // the adjacency pass: live lists and / or the decision
+    // sparse Eq. 8 of the user graph from LDS-staged rows (digat_staged.inc): needs the plan of the batch (units of centres)
+    const bool use_staged = L > 0 && g_staged_on && plan_ws && sparse_mode != DIGAT_XATTN_DENSE && U > 16 && staged_ok(U, d / 4);
+    const PlanBuffers plan = use_staged ? plan_carve(plan_ws, B, U) : PlanBuffers{};
     // live rows of the user graph for the projections of layers >= 1 (DIGAT_NO_SKIP=1: every row)
     const int* rowidx = nullptr;
     const int* nrows_dev = nullptr;
@@ -511,6 +520,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         DIGAT_CHECK_LAUNCH();
         pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1;
         return DIGAT_OK;
+    };
+    // the plan follows the live flags on the same stream (its second list is the live centres)
+    // one plan per distinct user graph: per group when the caller gave the user side per group, else per row
+    auto make_plan = [&](hipStream_t sq) -> int {
+        const bool per_group = row_group && Au_g && cm_g && ci_g;
+        return launch_plan(per_group ? Au_g : Au, per_group ? cm_g : cat_mask, per_group ? ci_g : cat_idx, per_group ? row_group : nullptr,
+                           B, per_group ? G : B, U, H, C1, d / 4, want_live, plan, sq);
     };
     auto publish_live_rows = [&]() {
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
@@ -584,15 +600,24 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
             return DIGAT_ERR_LAUNCH;
     }
+    const bool plan_early = side && use_staged;
+    if (side && plan_early && !(news_early || group_early || live_early)) {
+        if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
+            return DIGAT_ERR_LAUNCH;
+    }
     if (live_early) {                  // first: layer 0 may need the sparse / dense decision
         rc = find_live_rows(side->s);
+        if (rc) return rc;
+    }
+    if (plan_early) {
+        rc = make_plan(side->s);
         if (rc) return rc;
     }
     if (group_early) {
         rc = group_project(side->s);
         if (rc) return rc;
     }
-    if (group_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO)) {
+    if (group_early || plan_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO)) {
         if (hipEventRecord(side->early, side->s) != hipSuccess) return DIGAT_ERR_LAUNCH;
     }
     if (news_early && !news_hpq0) {      // news_hpq0: the caller kept layer 0's news projections per news (digat_news_project0)
@@ -622,7 +647,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = find_live_rows(st);
             if (rc) return rc;
         }
-        if (i == 0 && side && (group_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO))) {
+        if (i == 0 && use_staged && !plan_early) {
+            rc = make_plan(st);
+            if (rc) return rc;
+        }
+        if (i == 0 && side && (group_early || plan_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO))) {
             if (hipStreamWaitEvent(st, side->early, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
         }
         if (i == 0 && row_group) {
@@ -645,7 +674,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                     // the topic pooling after it reads (weight 0, but 0 * NaN = NaN), get X_i now
                                     (xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
                                     nullptr, nullptr, G, nullptr};
-                rc = launch_sparse(sg, st);
+                rc = use_staged ? launch_staged(sg, plan, 0, 0, st) : launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
                 const int* skip_if = sparse_mode == DIGAT_XATTN_AUTO && d / 4 <= 256 ? sparse_flag : nullptr;
@@ -666,7 +695,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
                             i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr, sparse_mode,
-                            sparse_flag, pq_x3);
+                            sparse_flag, pq_x3, use_staged ? &plan : nullptr, i);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
@@ -724,8 +753,9 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
     // live-node and live-bucket counts, offsets, lists (int) and flags (bytes)
     // + adjacency entries per row and the sparse / dense decision (int)
-    tot += (3 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
-            + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256);
+    tot += align_up((3 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
+                     + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256), 256);
+    tot += plan_bytes(B, U);                             // the staged Eq. 8 kernel's plan of the batch (digat_staged.inc)
     return tot;
 }
 
@@ -736,7 +766,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,
                             const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
                             void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
-                            const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr) {
+                            const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
+                            const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -768,6 +799,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     float* const r_user2[2] = {r_user, (float*)(ws + 4 * sb)};
     void* xws_news = ws + 5 * sb;
     int* live_ws = (int*)((char*)xws_news + digat_xattn_workspace_bytes(B, N, d));
+    void* plan_ws = (char*)workspace + digat_encoder_workspace_bytes(B, N, H, C, d, L) - plan_bytes(B, U);
 
     int rc;
     const bool folded = p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W;
@@ -799,7 +831,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -836,6 +868,14 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
 int digat_set_live_row_skipping(int enabled) {
     const int prev = g_live_rows_on;
     g_live_rows_on = enabled ? 1 : 0;
+    return prev;
+}
+
+int digat_set_staged_xattn(int mode) {
+    (void)staged_cfg();
+    const int prev = g_staged_on ? 1 + g_staged_cfg : 0;
+    g_staged_on = mode > 0 ? 1 : 0;
+    if (mode > 0 && mode <= 4) g_staged_cfg = mode - 1;
     return prev;
 }
 
@@ -885,7 +925,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0);
+                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g);
 }
 
 int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,

@@ -207,6 +207,17 @@ int digat_set_side_stream(int enabled);
  * are unchanged.  0 projects every row (also: env DIGAT_NO_SKIP=1).  Returns the previous setting. */
 int digat_set_live_row_skipping(int enabled);
 
+/* Sparse Eq. 8 of the user graph inside the encoder entry points, from LDS-staged rows (digat_staged.inc; needs the per-batch
+ * plan the entry points then build): the needed P' / h rows of a block of centres are staged once in LDS, so each is read
+ * from HBM once (PMC: 1.15x the algorithmic bytes, against 2-3x for the wave-per-centre kernel).
+ *   0  (default) the wave-per-centre kernel, which re-reads shared neighbour rows through L2 — still the faster one
+ *      (98 us against 120 us per user-graph launch, round 2: the staged kernels do not yet overlap their DMA with compute)
+ *   4  staged rows + one THREAD per adjacency entry for the scores (no cross-lane reduction; the channel sum is one
+ *      sequential fma chain: last-bit differences from mode 0, 2e-5 against the oracle)
+ *   1-3  staged rows + the wave-per-centre arithmetic (bit-identical to mode 0), three workgroup shapes
+ * Also: env DIGAT_XATTN_STAGED=1 (+ DIGAT_STAGED_CFG=0..3 = mode - 1).  Returns the previous mode. */
+int digat_set_staged_xattn(int mode);
+
 /* The same inference for rows that SHARE users: in dev/test scoring the ~37 candidate rows of one
  * impression carry identical user tensors (util.py:57-67 expands them per row).  Here the user side is
  * passed once per group — user_news_embedding [G,H,d], user_graph [G,U,U], user_category_mask [G,C+1],

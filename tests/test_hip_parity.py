@@ -403,6 +403,67 @@ def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     assert torch.equal(live_per_row, every)
 
 
+@pytest.mark.parametrize("shape", ["default", "large", "stress"])
+def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
+    """The LDS-staged sparse Eq. 8 kernel (one workgroup per block of centres, rows read once: digat_staged.inc) evaluates
+    every centre with the arithmetic of xattn_sparse_kernel in the same order: whole dev runs must agree bit for bit —
+    grouped (layer 0 through the group index, K3 added to the staged rows) and per row, live lists on and off; the corpus
+    holds empty-history users, and long single-category histories make units that are cut by rows and by entries."""
+    from digat_amd import _lib, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    nb, hops, L, C = {"default": (3, 2, 3, 17), "large": (5, 2, 3, 18), "stress": (8, 2, 4, 17)}[shape]
+    spec = synthetic.SynthSpec(news_num=1500, sag_neighbors=nb, sag_hops=hops, category_num=C, impressions=60,
+                               mean_candidates=30.0, max_candidates=80, seed=111)
+    corpus = synthetic.make_corpus(spec)
+    # two users whose whole history sits in one category (50 + 1 needed rows: more than LDS holds -> "direct" units) and one
+    # with two big categories (units cut by rows)
+    H = spec.max_history_num
+    for imp, cats in ((2, np.zeros(H, dtype=np.int64)), (5, np.full(H, 3, dtype=np.int64)),
+                      (7, np.r_[np.zeros(H // 2, dtype=np.int64), np.ones(H - H // 2, dtype=np.int64)])):
+        g, cm, ci = synthetic.build_user_graphs(cats[None, :], np.array([H]), C)
+        corpus.user_graph[imp], corpus.user_category_mask[imp], corpus.user_category_indices[imp] = g[0], cm[0], ci[0]
+        corpus.history[imp] = np.arange(1, H + 1)
+    state = synthetic.make_state_dict(spec.embedding_dim, C, L, seed=112, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=H, category_num=C, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    model.graph_encoder.user_xattn_mode = "sparse"
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    lib = _lib.lib()
+    prev = lib.digat_set_staged_xattn(0)
+    try:
+        plain = util.score_rows(model, dc, 0, dc.rows, 1024)
+        plain_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+        got = {}
+        for mode in (3, 1, 4):                       # wave-per-centre arithmetic from staged rows (two shapes), thread-per-entry scores
+            lib.digat_set_staged_xattn(mode)
+            got[mode, "grouped"] = util.score_rows(model, dc, 0, dc.rows, 1024)
+            got[mode, "per row"] = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+            skip_prev = lib.digat_set_live_row_skipping(0)
+            got[mode, "every row"] = util.score_rows(model, dc, 0, dc.rows, 1024)
+            lib.digat_set_live_row_skipping(skip_prev)
+        hint = dict(model.graph_encoder.corpus_xattn_hint)
+        model.graph_encoder.user_xattn_mode = "auto"
+        model.graph_encoder.corpus_xattn_hint = {k: v for k, v in hint.items() if k != "user"}
+        assert model.graph_encoder.resolved_xattn_mode("user") == "auto"    # the device decides; both variants are launched
+        got[4, "auto"] = util.score_rows(model, dc, 0, dc.rows, 1024)
+    finally:
+        lib.digat_set_staged_xattn(prev)
+    assert torch.equal(plain, plain_per_row)
+    for (mode, how), scores in got.items():
+        assert torch.isfinite(scores).all(), (mode, how)
+        if mode != 4:
+            assert torch.equal(scores, plain), (mode, how, float((scores - plain).abs().max()))
+        else:       # a sequential channel sum instead of the lane tree: the last bits move (logits are O(100-1000) here)
+            err = ((scores - plain).abs() / (1e-3 + plain.abs())).max().item()
+            assert err < 2e-5, (how, err)
+    assert torch.equal(got[4, "grouped"], got[4, "per row"]) and torch.equal(got[4, "grouped"], got[4, "every row"])
+    assert torch.equal(got[4, "grouped"], got[4, "auto"])
+
+
 def test_encoder_call_is_graph_capturable():
     """include/digat_hip.h promises: no allocation, no host synchronisation, side stream forked and joined through
     events — so one encoder call can be captured into a hipGraph and replayed.  Replay must reproduce the eager bits."""
