@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "../../include/digat_hip.h"
 
@@ -402,20 +403,30 @@ static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGA
 // 0 (default): the wave-per-centre sparse kernel; 1: the LDS-staged kernels of digat_staged.inc (compulsory HBM traffic, measured
 // slower in round 2: DESIGN.md section 4)
 static int g_staged_on = getenv("DIGAT_XATTN_STAGED") ? atoi(getenv("DIGAT_XATTN_STAGED")) : 0;
-static SideStream* side_stream() {
-    static SideStream tab[16];
-    static int state[16];                    // 0 = untried, 1 = ready, -1 = unavailable
+// One side stream (and its three events) per CALLER stream: consecutive batches issued on alternating caller streams
+// (util.batch_streams) then overlap their side work too, and two host threads driving two streams never touch the same
+// events.  A caller stream is expected to be driven by one thread at a time (include/digat_hip.h, threading contract); the
+// table itself is guarded by a mutex.  Entries live for the life of the process (streams are few and long-lived).
+static SideStream* side_stream(hipStream_t caller) {
+    struct Entry { int dev; hipStream_t caller; SideStream side; int state; };     // state: 1 = ready, -1 = unavailable
+    static Entry tab[64];
+    static int used = 0;
+    static std::mutex mu;
     int dev = 0;
-    if (!g_side_stream_on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (state[dev] == 0) {                   // one process per GPU; a race here would only create a spare stream
-        SideStream& x = tab[dev];
-        const bool ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-                        hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&x.early, hipEventDisableTiming) == hipSuccess;
-        state[dev] = ok ? 1 : -1;
-    }
-    return state[dev] == 1 ? &tab[dev] : nullptr;
+    if (!g_side_stream_on || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (tab[i].dev == dev && tab[i].caller == caller) return tab[i].state == 1 ? &tab[i].side : nullptr;
+    if (used == 64) return nullptr;            // more caller streams than anyone has: those run single-stream
+    Entry& e = tab[used++];
+    e.dev = dev; e.caller = caller;
+    SideStream& x = e.side;
+    const bool ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&x.early, hipEventDisableTiming) == hipSuccess;
+    e.state = ok ? 1 : -1;
+    return ok ? &x : nullptr;
 }
 
 static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
@@ -531,7 +542,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     auto publish_live_rows = [&]() {
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
     };
-    SideStream* side = side_stream();
+    SideStream* side = side_stream(st);
     // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
     // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
     // layer i+1's under the pooling of user context i — instead of waiting for c_u.
