@@ -1068,6 +1068,7 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 }  // extern "C"
 
 #include "digat_train.inc"
+#include "digat_train_abi.inc"
 #include "digat_eval.inc"
 #include "digat_news.inc"
 #include "digat_gat.inc"

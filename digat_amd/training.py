@@ -2,14 +2,18 @@
 
 The reference trains by plain autograd through ``graphEncoders.DIGAT.forward`` (trainer.py:98-102).
 Here the same forward (graphEncoders.py:177-187, with its three dropouts live) is composed from a small
-set of ``torch.autograd.Function``s whose forward AND backward are kernels of ``libdigat_hip.so``:
+set of ``torch.autograd.Function``s whose forward AND backward are calls into ``libdigat_hip.so``:
 
-    Linear / MatmulW      nn.Linear and x @ K (the folded-away key projection, unfolded for training)
-    AttnPool, TopicPool   ScaledDotProductAttention pooling, scatter_softmax + scatter_sum
-    GateMix, ReluRes      sigmoid gate mix, relu(y) + t
-    Dropout               counter-hash dropout (own RNG: masks differ from torch's, statistics do not)
-    XattnLayer            Eq. 8: projections + score/softmax/aggregate; the backward RECOMPUTES
+    XattnFused            Eq. 8 layer: K3, projections, score / softmax / attention dropout / aggregation
+                          (``digat_xattn_fwd_train`` / ``digat_xattn_bwd``); the backward RECOMPUTES
                           relu'(K3+K1+K2) from the saved projections, [B,n,n,d] is never stored
+    NewsCtxFused          compute_news_graph_context (``digat_news_ctx_fwd_train`` / ``digat_news_ctx_bwd``)
+    UserCtxFused          compute_user_graph_context (``digat_user_ctx_fwd_train`` / ``digat_user_ctx_bwd``)
+    Dropout               counter-hash dropout (own RNG: masks differ from torch's, statistics do not)
+
+One library call per function and direction: a training step is ~45 calls from the host; the
+finer-grained Functions below (Linear, MatmulW, AttnPool, TopicPool, GateMix, ReluRes, XattnLayer) wrap the primitives
+those calls are composed of and are kept for tests and for callers that build other encoders from them.
 
 PyTorch does what it does for the reference too: owns the tensors, records the graph, and runs the
 few pure data-movement ops (``cat``, ``select``, ``expand``, ``+`` of two contexts).  There is no
@@ -323,41 +327,153 @@ class XattnLayer(Function):
 
 
 # --------------------------------------------------------------------------------------------------
+# the three functions of the path, one library call per direction (include/digat_hip.h: digat_*_fwd_train / digat_*_bwd)
+# --------------------------------------------------------------------------------------------------
+def _save_buffer(nbytes, dev):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+class XattnFused(Function):
+    """Eq. 8 layer on already-dropped-out inputs Xd (graphEncoders.py:143-154): K3, the projections, score / softmax /
+    attention dropout / aggregation in ``digat_xattn_fwd_train``; the whole backward — pairwise (recomputing
+    relu'(K3+K1+K2)), the three projection backwards, K3's — in ``digat_xattn_bwd``."""
+
+    @staticmethod
+    def forward(ctx, Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p_alpha):
+        Xd, cvec = _f(Xd), _f(cvec)
+        B, n, d = Xd.shape
+        dev = Xd.device
+        out = torch.empty_like(Xd)
+        nsave, nws = L().digat_xattn_train_save_bytes(B, n, d), L().digat_xattn_train_workspace_bytes(B, n, d)
+        save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
+        p = float(p_alpha)
+        _lib.check(L().digat_xattn_fwd_train(Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
+                                             F2.data_ptr(), F3.data_ptr(), b3.data_ptr(), a.data_ptr(), out.data_ptr(), p,
+                                             _seed() if p > 0 else 0, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, S()),
+                   "digat_xattn_fwd_train")
+        ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
+        ctx.p, ctx.sizes = p, (nsave, nws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        Xd, A, cvec, W, F1, F2, F3, a, out, save = ctx.saved_tensors
+        B, n, d = Xd.shape
+        dev = Xd.device
+        dOut = _f(dOut)
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dX, dc = torch.empty_like(Xd), torch.empty_like(cvec)
+        dW, dF1, dF2, dF3 = (torch.empty_like(W) for _ in range(4))
+        dbW, db3, da = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+        _lib.check(L().digat_xattn_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(),
+                                       F1.data_ptr(), F2.data_ptr(), F3.data_ptr(), a.data_ptr(), ctx.p, save.data_ptr(), nsave,
+                                       dX.data_ptr(), dc.data_ptr(), dW.data_ptr(), dbW.data_ptr(), dF1.data_ptr(), dF2.data_ptr(),
+                                       dF3.data_ptr(), db3.data_ptr(), da.data_ptr(), B, n, d, ws.data_ptr(), nws, S()),
+                   "digat_xattn_bwd")
+        return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None
+
+
+class NewsCtxFused(Function):
+    """compute_news_graph_context (graphEncoders.py:109-114), training mode."""
+
+    @staticmethod
+    def forward(ctx, X, mask, Kc, Qc, bQc, Wg, bg, p_gate):
+        X = _f(X)
+        B, N, d = X.shape
+        dev = X.device
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        nsave, nws = L().digat_news_ctx_train_save_bytes(B, N, d), L().digat_news_ctx_train_workspace_bytes(B, N, d)
+        save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
+        p = float(p_gate)
+        _lib.check(L().digat_news_ctx_fwd_train(X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), bQc.data_ptr(),
+                                                Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), p, _seed() if p > 0 else 0, B, N, d,
+                                                save.data_ptr(), nsave, ws.data_ptr(), nws, S()), "digat_news_ctx_fwd_train")
+        ctx.save_for_backward(X, mask, Kc, Qc, Wg, save)
+        ctx.p, ctx.sizes = p, (nsave, nws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        X, mask, Kc, Qc, Wg, save = ctx.saved_tensors
+        B, N, d = X.shape
+        dev = X.device
+        dout = _f(dout)
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dX = torch.empty_like(X)
+        dKc, dQc, dWg = torch.empty_like(Kc), torch.empty_like(Qc), torch.empty_like(Wg)
+        dbQc, dbg = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(2))
+        _lib.check(L().digat_news_ctx_bwd(dout.data_ptr(), X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), Wg.data_ptr(),
+                                          ctx.p, save.data_ptr(), nsave, dX.data_ptr(), dKc.data_ptr(), dQc.data_ptr(), dbQc.data_ptr(),
+                                          dWg.data_ptr(), dbg.data_ptr(), B, N, d, ws.data_ptr(), nws, S()), "digat_news_ctx_bwd")
+        return dX, None, dKc, dQc, dbQc, dWg, dbg, None
+
+
+class UserCtxFused(Function):
+    """compute_user_graph_context (graphEncoders.py:123-134), training mode."""
+
+    @staticmethod
+    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic):
+        Xu, c_n = _f(Xu), _f(c_n)
+        B, U, d = Xu.shape
+        dev = Xu.device
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        nsave = L().digat_user_ctx_train_save_bytes(B, U, H, C1, d)
+        nws = L().digat_user_ctx_train_workspace_bytes(B, U, H, C1, d)
+        save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
+        p = float(p_topic)
+        _lib.check(L().digat_user_ctx_fwd_train(Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(), Ku.data_ptr(),
+                                                Qu.data_ptr(), bQu.data_ptr(), Fa.data_ptr(), bFa.data_ptr(), Kua.data_ptr(),
+                                                Qua.data_ptr(), bQua.data_ptr(), out.data_ptr(), p, _seed() if p > 0 else 0,
+                                                B, U, H, C1, d, save.data_ptr(), nsave, ws.data_ptr(), nws, S()),
+                   "digat_user_ctx_fwd_train")
+        ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
+        ctx.p, ctx.sizes, ctx.dims = p, (nsave, nws), (H, C1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save = ctx.saved_tensors
+        B, U, d = Xu.shape
+        H, C1 = ctx.dims
+        dev = Xu.device
+        dout = _f(dout)
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
+        dKu, dQu, dFa, dKua, dQua = (torch.empty_like(Ku) for _ in range(5))
+        dbQu, dbFa, dbQua = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+        _lib.check(L().digat_user_ctx_bwd(dout.data_ptr(), Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(),
+                                          Ku.data_ptr(), Qu.data_ptr(), Fa.data_ptr(), Kua.data_ptr(), Qua.data_ptr(), ctx.p,
+                                          save.data_ptr(), nsave, dXu.data_ptr(), dc.data_ptr(), dKu.data_ptr(), dQu.data_ptr(),
+                                          dbQu.data_ptr(), dFa.data_ptr(), dbFa.data_ptr(), dKua.data_ptr(), dQua.data_ptr(),
+                                          dbQua.data_ptr(), B, U, H, C1, d, ws.data_ptr(), nws, S()), "digat_user_ctx_bwd")
+        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
 # the reference's four functions, training mode
 # --------------------------------------------------------------------------------------------------
 def news_graph_context(enc, X, mask_bytes, p, training=True):
-    ca = enc.candidate_attention
-    local = X[:, 0]                                                   # select: a strided view, no copy
-    qv = Linear.apply(local, ca.Q.weight, ca.Q.bias)
-    kq = MatmulW.apply(qv, ca.K.weight)
-    glob = AttnPool.apply(X, kq, mask_bytes)
-    z = Linear.apply(torch.cat([local, glob], dim=1), enc.news_graph_W.weight, enc.news_graph_W.bias)
-    z = dropout(z, p / 2, training)
-    return GateMix.apply(z, local, glob)
+    ca, g = enc.candidate_attention, enc.news_graph_W
+    return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0)
 
 
 def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True):
-    H, C1 = enc.max_history_num, enc.category_num
-    d = Xu.shape[2]
-    qv = Linear.apply(c_n, enc.user_news_Q.weight, enc.user_news_Q.bias)
-    kq = MatmulW.apply(qv, enc.user_news_K.weight)
-    T = TopicPool.apply(Xu, kq, cat_idx, H, C1)
-    y = Linear.apply(T.view(-1, d), enc.featureAffine.weight, enc.featureAffine.bias).view_as(T)
-    T2 = dropout(ReluRes.apply(y, T), p, training)
-    ua = enc.userAttention
-    qv2 = Linear.apply(c_n, ua.Q.weight, ua.Q.bias)
-    kq2 = MatmulW.apply(qv2, ua.K.weight)
-    return AttnPool.apply(T2, kq2, cat_mask_bytes)
+    ua, fa = enc.userAttention, enc.featureAffine
+    return UserCtxFused.apply(Xu, cat_mask_bytes, cat_idx, c_n, enc.user_news_K.weight, enc.user_news_Q.weight, enc.user_news_Q.bias,
+                              fa.weight, fa.bias, ua.K.weight, ua.Q.weight, ua.Q.bias, enc.max_history_num, enc.category_num,
+                              p if training else 0.0)
 
 
 def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True):
     Xd = dropout(X, p / 2, training)
     F3 = getattr(enc, f"{g}_graph_attention_ffn3")[i]
     W = getattr(enc, f"{g}_graph_attention_W")[i]
-    r = Linear.apply(ctx_vec, F3.weight, F3.bias)
-    return XattnLayer.apply(Xd, A_bytes, r, W.weight, W.bias,
+    return XattnFused.apply(Xd, A_bytes, ctx_vec, W.weight, W.bias,
                             getattr(enc, f"{g}_graph_attention_ffn1")[i].weight,
-                            getattr(enc, f"{g}_graph_attention_ffn2")[i].weight,
+                            getattr(enc, f"{g}_graph_attention_ffn2")[i].weight, F3.weight, F3.bias,
                             getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0)
 
 

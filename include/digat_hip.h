@@ -309,6 +309,48 @@ int digat_xattn_pairwise_bwd(const float* dOut, const float* out, const float* X
                              void* stream);
 int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* stream);          /* dr[b] = sum_j dP[b,j] */
 
+/* ---- training: the three functions of the path as one forward and one backward call each ----------------
+ * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one
+ * autograd.Function.  `save` is a caller-owned buffer carrying what the backward needs from the forward (private layout,
+ * *_save_bytes); `workspace` is scratch (*_workspace_bytes, the same size for both directions).  Dropout: the library's
+ * counter-hash generator with the caller's seed; p = 0 disables it.  Gradients are WRITTEN (not accumulated) and
+ * bit-reproducible (ordered reductions).
+ *
+ * a1 / a2 (graphEncoders.py:143-154, :163-174).  X is the layer input AFTER its input dropout drop_{p/2} (the residual uses
+ * the dropped input); out = relu(drop_p(alpha) h) + X.  The backward recomputes relu'(K3+K1+K2) from the saved projections. */
+size_t digat_xattn_train_save_bytes(int B, int n, int d);
+size_t digat_xattn_train_workspace_bytes(int B, int n, int d);
+int digat_xattn_fwd_train(const float* X, const uint8_t* A, const float* ctx, const float* W, const float* bW, const float* F1,
+                          const float* F2, const float* F3, const float* b3, const float* a, float* out, float p_alpha,
+                          uint32_t seed, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int digat_xattn_bwd(const float* dOut, const float* out, const float* X, const uint8_t* A, const float* ctx, const float* W,
+                    const float* F1, const float* F2, const float* F3, const float* a, float p_alpha, const void* save,
+                    size_t save_bytes, float* dX, float* dctx, float* dW, float* dbW, float* dF1, float* dF2, float* dF3,
+                    float* db3, float* da, int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
+/* a3 (graphEncoders.py:109-114): out = gate(drop_{p_gate}(W_g [l ; g] + b_g), l, g), l = X[:,0], g = candidate_attention(X, l). */
+size_t digat_news_ctx_train_save_bytes(int B, int N, int d);
+size_t digat_news_ctx_train_workspace_bytes(int B, int N, int d);
+int digat_news_ctx_fwd_train(const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* bQc,
+                             const float* Wg, const float* bg, float* out, float p_gate, uint32_t seed, int B, int N, int d,
+                             void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int digat_news_ctx_bwd(const float* dout, const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* Wg,
+                       float p_gate, const void* save, size_t save_bytes, float* dX, float* dKc, float* dQc, float* dbQc,
+                       float* dWg, float* dbg, int B, int N, int d, void* workspace, size_t workspace_bytes, void* stream);
+/* a4 (+a6, a7) (graphEncoders.py:123-134): topic pooling (scatter_softmax + scatter_sum), featureAffine + relu + residual,
+ * drop_{p_topic}, userAttention.  dXu [B,U,d]: history rows get the pooling's gradient, topic rows zero. */
+size_t digat_user_ctx_train_save_bytes(int B, int U, int H, int C1, int d);
+size_t digat_user_ctx_train_workspace_bytes(int B, int U, int H, int C1, int d);
+int digat_user_ctx_fwd_train(const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n, const float* Ku,
+                             const float* Qu, const float* bQu, const float* Fa, const float* bFa, const float* Kua,
+                             const float* Qua, const float* bQua, float* out, float p_topic, uint32_t seed, int B, int U, int H,
+                             int C1, int d, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int digat_user_ctx_bwd(const float* dout, const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n,
+                       const float* Ku, const float* Qu, const float* Fa, const float* Kua, const float* Qua, float p_topic,
+                       const void* save, size_t save_bytes, float* dXu, float* dc_n, float* dKu, float* dQu, float* dbQu,
+                       float* dFa, float* dbFa, float* dKua, float* dQua, float* dbQua, int B, int U, int H, int C1, int d,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- H2: ranking + metrics of the dev/test driver  (util.py:70-80, evaluate.py:32-89) -------------------
  * scores [R] f32 in impression-major row order; impression_start [I+1] int64 (row offsets; impression i owns
  * rows [start[i], start[i+1])).  ranks [R] int32 receives the 1-based rank of every candidate after a STABLE

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/r02k
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r02k/pytest.log 2>&1
-python bench.py --extra-steps 0 --cpu-rows 0 --steps 30 > gpurun_out/r02k/b.json 2>/dev/null
-python bench.py --extra-steps 0 --cpu-rows 0 --steps 30 > gpurun_out/r02k/b2.json 2>/dev/null
-tail -n 5 gpurun_out/r02k/pytest.log
+mkdir -p gpurun_out/r02l
+timeout 900 python -m pytest tests/test_hip_training.py tests/test_hip_ddp.py -m gpu -x -q > gpurun_out/r02l/pytest.log 2>&1
+python tools/train_bench.py > gpurun_out/r02l/train.txt 2>&1
+tail -n 25 gpurun_out/r02l/pytest.log; cat gpurun_out/r02l/train.txt | tail -n 3
