@@ -83,8 +83,9 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=12, help="timed steps of each extra workload at N=1 (0 = skip)")
     ap.add_argument("--per-row-users", action="store_true",
                     help="expand the user tensors per row as the reference's driver does (default: once per impression)")
-    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32"],
-                    help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA")
+    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1"],
+                    help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
+                         "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one)")
     return ap.parse_args()
 
 
@@ -331,7 +332,7 @@ def rooflines(W, run, args):
     # chip is shared by two batches and the side stream, and a launch's duration there says how long it waited, not what it cost
     iso_ms = {k: prof_iso[k]["ms"] / max(1, run.iso_steps) for k in kinds if prof_iso.get(k, {}).get("launches", 0) > 0}
     dom = max(iso_ms, key=iso_ms.get) if iso_ms else max(kinds, key=lambda k: kinds[k]["ms"])
-    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(enc, "projection_mode", "").startswith("bf16x6")
+    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(enc, "projection_mode", "") != "fp32"
                else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>",
                "xattn": "xattn_sparse" if enc.resolved_xattn_mode("user") == "sparse" else "xattn_score_kernel",
                "agg": "xattn_agg_kernel", "topic": "topic_pool", "pool": "attn_pool_kernel"}
@@ -356,16 +357,17 @@ def rooflines(W, run, args):
         per_launch_ms = v["ms"] / v["launches"]
         rate = v["work"] / (v["ms"] * 1e-3)
         pmode = getattr(enc, "projection_mode", "fp32")
-        if kind == "proj" and pmode.startswith("bf16x6"):
+        if kind == "proj" and pmode != "fp32":
             # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split; "bf16x6-pq3": 6 for h,
             # 3 for P and Q = 4 on average): price the EXECUTED bf16 flops against the dense bf16 peak, and quote the
             # fp32-equivalent rate
-            nprod = 6 if pmode == "bf16x6" else 4
+            nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-bf16-x1": 8.0 / 3.0}[pmode]
             return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": nprod * rate / 1e12,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": nprod * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": pmc_traffic(kind),
                     "mfma_dtype": "bf16 (3-way split of f32, f32 accumulate; products per fp32 product: %s)"
-                                  % ("6" if nprod == 6 else "6 for h, 3 for P and Q"),
+                                  % {"bf16x6": "6", "bf16x6-pq3": "6 for h, 3 for P and Q", "pq-bf16": "6 for h, 3 for P and Q",
+                                     "pq-bf16-x1": "6 for h, 1 for P and Q (user graph, layers >= 1)"}[pmode],
                     "fp32_equivalent_tflops": rate / 1e12, "algorithmic_flops_per_launch": v["work"] / v["launches"],
                     "executed_flops_per_launch": nprod * v["work"] / v["launches"],
                     "peak_note": "nominal dense bf16 peak (2.4 GHz); on random operands the chip holds about 1.9-2.0 GHz "
@@ -551,7 +553,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not args.projection.startswith("pq-bf16") else "f32 with P', Q of the user graph's Eq. 8 in bf16 (configs[4])",
         "data": "synthetic",
         "valid": bool(matched or auc_match is None),
         "config": workload_config(W, args, D),

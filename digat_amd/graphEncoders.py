@@ -73,7 +73,9 @@ class DIGAT(GraphEncoder):
             setattr(self, f"{g}_graph_attention_a", nn.ModuleList([nn.Linear(d, 1, bias=False) for _ in range(L)]))
         self._param_block = None
         # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default), "bf16x6-pq3" = the same
-        # for h, three of the six products for P and Q (they only feed the score: DIGAT_PROJ_PQ_X3), "fp32" = v_mfma_f32_16x16x4_f32
+        # for h, three of the six products for P and Q (they only feed the score: DIGAT_PROJ_PQ_X3), "fp32" = v_mfma_f32_16x16x4_f32;
+        # BASELINE configs[4]: "pq-bf16" = pq3 + P', Q of the user graph's layers >= 1 STORED in bf16 (DIGAT_PQ_BF16; the
+        # reference's quantised K3 + K1 + K2, README.md:62-66), "pq-bf16-x1" = the same with one bf16 product for P and Q
         self.projection_mode = "bf16x6"
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
@@ -157,7 +159,7 @@ class DIGAT(GraphEncoder):
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
         # bf16x6 projections: split [W | ffn1 | ffn2] of every layer into three bf16 planes (once per weight version)
         P._splits = []
-        if self.projection_mode in ("bf16x6", "bf16x6-pq3") and self.news_embedding_dim % 80 == 0:
+        if self.projection_mode in ("bf16x6", "bf16x6-pq3", "pq-bf16", "pq-bf16-x1") and self.news_embedding_dim % 80 == 0:
             L_ = _lib.lib()
             d = self.news_embedding_dim
             nbytes = L_.digat_split_weights_bytes(3 * d, d)
@@ -188,9 +190,12 @@ class DIGAT(GraphEncoder):
     def _flags(self) -> int:
         """digat_params.flags (include/digat_hip.h): Eq. 8 variant of the user graph (bits 0-1), DIGAT_PROJ_PQ_X3 (bit 2),
         DIGAT_NEWS_XATTN_SPARSE (bit 3)."""
+        pm = self.projection_mode
         return ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
-                | (4 if self.projection_mode == "bf16x6-pq3" else 0)
-                | (8 if self.resolved_xattn_mode("news") == "sparse" else 0))
+                | (4 if pm in ("bf16x6-pq3", "pq-bf16") else 0)
+                | (8 if self.resolved_xattn_mode("news") == "sparse" else 0)
+                | (16 if pm in ("pq-bf16", "pq-bf16-x1") else 0)         # DIGAT_PQ_BF16: P', Q of Eq. 8 stored in bf16
+                | (32 if pm == "pq-bf16-x1" else 0))                     # DIGAT_PQ_X1: ... and computed with one bf16 product
 
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention

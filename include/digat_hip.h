@@ -136,6 +136,13 @@ enum { DIGAT_PROJ_PQ_X3 = 4 };
  * ones always take the wave-per-centre small-graph kernel).  SAG news graphs are breadth-first trees plus a few cross
  * edges: 3-4 entries per node at N = 26 or 65. */
 enum { DIGAT_NEWS_XATTN_SPARSE = 8 };
+/* digat_params.flags bit 4 (BASELINE configs[4]; folded inference path, bf16x6 projections, sparse Eq. 8 of the user graph,
+ * layers >= 1 — the two launches that carry most of the bytes): the projection GEMM stores P' = K3 + K1 and Q = K2 in bf16
+ * (round to nearest even) and the Eq. 8 kernel reads them as such; the score is still accumulated in fp32, h (the values), X
+ * and every output stay fp32.  This is the reference's own "faster inference" idea — a quantised K3 + K1 + K2
+ * (README.md:62-66).  Ranking metrics move by < 1e-4 (tests/test_hip_lowprec.py); element-wise the contexts move by ~1e-4.
+ * Bit 5: the P and Q segments with the leading bf16 product alone (2^-8 per product) instead of the number bit 2 selects. */
+enum { DIGAT_PQ_BF16 = 16, DIGAT_PQ_X1 = 32 };
 
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */

@@ -245,3 +245,31 @@ def test_train_step_at_production_shapes():
     close(ue.grad.numpy(), fx["g_in_user_news_embedding"], "dX_user")
     for k, v in p.items():
         check_grad_digest(fx, k, v.grad.numpy(), 2e-5, "oracle grad ")
+
+
+def test_oracle_on_a_slice_of_the_2k_devset():
+    """devset_2k.npz (2 000 impressions scored by the reference): the oracle on its first impressions (a CPU-sized slice);
+    the GPU suite holds the HIP path to all 74 k rows (tests/test_hip_lowprec.py)."""
+    from digat_amd import synthetic
+    fx = load_golden("devset_2k.npz")
+    spec = synthetic.SynthSpec(news_num=4096, sag_neighbors=3, sag_hops=2, impressions=2000, seed=47)
+    corpus = synthetic.make_corpus(spec)
+    L = int(fx["depth"])
+    p = O.as_params(synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=spec.seed + 1, bias_std=0.05))
+    rows = int(np.searchsorted(corpus.row_impression, 8))            # the first 8 impressions
+    emb = torch.from_numpy(corpus.news_embedding)
+    cand = torch.from_numpy(corpus.row_candidate[:rows].astype(np.int64))
+    ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64)).index_select(0, cand)
+    sa = emb.index_select(0, ids.flatten()).view(rows, -1, spec.embedding_dim)
+    masks = torch.from_numpy(corpus.news_graph_mask).index_select(0, cand)
+    graphs = torch.from_numpy(corpus.news_graph).index_select(0, cand)
+    imp = torch.from_numpy(corpus.row_impression[:rows])
+    hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+    ue = emb.index_select(0, hist.flatten()).view(rows, spec.max_history_num, spec.embedding_dim)
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        got = O.row_logits(p, L, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                           torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                           torch.from_numpy(corpus.user_category_indices).index_select(0, imp), sa, graphs, masks, c_n0).numpy()
+    want = fx["scores"][:rows]
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-4), np.abs(got - want).max()

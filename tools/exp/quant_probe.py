@@ -1,0 +1,62 @@
+"""CPU probe (oracle arithmetic): how far do the scores and the ranking metrics move when K1(+K3) and K2 of Eq. 8 are stored in
+bf16 / fp8-e4m3 (per-row scale) before the broadcast-add?  configs[4] of BASELINE.json; README.md:62-66 of the reference."""
+import os, sys, time
+import numpy as np, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from digat_amd import synthetic, evaluate
+from oracle import digat_oracle as O
+
+def q_bf16(x): return x.to(torch.bfloat16).to(torch.float32)
+def q_fp8(x):
+    s = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) / 448.0
+    return (x / s).to(torch.float8_e4m3fn).to(torch.float32) * s
+MODES = {"fp32": (lambda x: x), "bf16": q_bf16, "fp8": q_fp8}
+STATE = {"q": MODES["fp32"], "graphs": ("user",), "h": False}
+def xattn(p, graph, layer, X, adj, ctx, return_alpha=False):
+    B, n, d = X.shape
+    pre = f"{graph}_graph_attention_"
+    h = O._linear(X, p, f"{pre}W.{layer}")
+    q = STATE["q"] if graph in STATE["graphs"] else (lambda x: x)
+    K3 = O._linear(ctx, p, f"{pre}ffn3.{layer}").view(B, 1, d)
+    K1 = q(K3 + O._linear(X, p, f"{pre}ffn1.{layer}")).unsqueeze(1)
+    K2 = q(O._linear(X, p, f"{pre}ffn2.{layer}")).unsqueeze(2)
+    if STATE["h"] and graph in STATE["graphs"]: h = q_bf16(h)
+    s = F.linear(F.relu(K1 + K2), p[f"{pre}a.{layer}.weight"]).squeeze(3)
+    e = F.leaky_relu(s, 0.2)
+    alpha = F.softmax(e.masked_fill(adj == 0, O.MASK_FILL), dim=2)
+    return F.relu(torch.bmm(alpha, h)) + X
+O.cross_graph_attention = xattn
+
+imps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=imps, seed=47)
+corpus = synthetic.make_corpus(spec); L = 3
+state = synthetic.make_state_dict(400, 17, L, seed=48, bias_std=0.05)
+p = O.as_params(state)
+emb = torch.from_numpy(corpus.news_embedding)
+ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
+sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, 400)
+masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+def run():
+    out = []
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        for s in range(0, corpus.rows, 64):
+            e = min(s + 64, corpus.rows)
+            imp = torch.from_numpy(corpus.row_impression[s:e]); cand = torch.from_numpy(corpus.row_candidate[s:e].astype(np.int64))
+            hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+            ue = emb.index_select(0, hist.flatten()).view(e - s, 50, 400)
+            out.append(O.row_logits(p, L, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                                    torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                                    torch.from_numpy(corpus.user_category_indices).index_select(0, imp),
+                                    sa.index_select(0, cand), graphs.index_select(0, cand), masks.index_select(0, cand), c_n0.index_select(0, cand)))
+    return torch.cat(out).numpy()
+def metrics(sc):
+    ri = corpus.row_impression
+    return np.array(evaluate.scoring(corpus.row_label, evaluate.impression_ranks(sc, ri), ri))
+torch.set_num_threads(8)
+base = run(); mb = metrics(base)
+print("rows", corpus.rows, "fp32 metrics", mb, "score scale", np.abs(base).mean())
+for name, graphs_, hq in (("bf16", ("user",), False), ("bf16", ("user", "news"), False), ("bf16", ("user", "news"), True), ("fp8", ("user",), False), ("fp8", ("user", "news"), False)):
+    STATE.update(q=MODES[name], graphs=graphs_, h=hq)
+    sc = run(); m = metrics(sc)
+    print(f"{name:5s} graphs={graphs_} h_bf16={hq}: max rel score diff {np.max(np.abs(sc-base)/(np.abs(base)+1e-3)):.2e}  mean {np.mean(np.abs(sc-base)/(np.abs(base)+1e-3)):.2e}  metric drift {np.abs(m-mb).max():.2e} {np.round(m-mb,6)}")
