@@ -159,7 +159,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
-                      int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0) {
+                      int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -186,7 +186,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
         const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
                             sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
-                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq16 ? 1 : 0};
+                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq16 ? 1 : 0, plan ? 0 : centre_limit};
         // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
         const int rcs = plan ? launch_staged(sg, *plan, listed && live ? 1 : 0, plan_slot, st) : launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
@@ -688,7 +688,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                     // Xu[0] was never written: the rows of dead nodes, which layer 1 will not write there and
                                     // the topic pooling after it reads (weight 0, but 0 * NaN = NaN), get X_i now
                                     (xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
-                                    nullptr, nullptr, G, nullptr, 0};
+                                    nullptr, nullptr, G, nullptr, 0, 0};
                 rc = use_staged ? launch_staged(sg, plan, 0, 0, st) : launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
@@ -711,7 +711,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
                             i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr, sparse_mode,
                             sparse_flag, pq_x3, use_staged ? &plan : nullptr, i,
-                            i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) : 0);
+                            i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) : 0,
+                            // after the last layer only the history rows are read (the user context's topic pooling, :124):
+                            // the topic nodes' own Eq. 8 is not computed there (wave-per-centre sparse kernel)
+                            (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
