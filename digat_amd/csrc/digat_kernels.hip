@@ -894,7 +894,7 @@ int digat_set_staged_xattn(int mode) {
     (void)staged_cfg();
     const int prev = g_staged_on ? 1 + g_staged_cfg : 0;
     g_staged_on = mode > 0 ? 1 : 0;
-    if (mode > 0 && mode <= 4) g_staged_cfg = mode - 1;
+    if (mode > 0 && mode <= 5) g_staged_cfg = mode - 1;
     return prev;
 }
 

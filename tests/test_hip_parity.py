@@ -438,7 +438,7 @@ def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
         plain = util.score_rows(model, dc, 0, dc.rows, 1024)
         plain_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
         got = {}
-        for mode in (3, 1, 4):                       # wave-per-centre arithmetic from staged rows (two shapes), thread-per-entry scores
+        for mode in (3, 1, 4, 5):                    # wave-per-centre arithmetic from staged rows (two shapes), thread-per-entry scores, pipelined
             lib.digat_set_staged_xattn(mode)
             got[mode, "grouped"] = util.score_rows(model, dc, 0, dc.rows, 1024)
             got[mode, "per row"] = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
@@ -449,19 +449,21 @@ def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
         model.graph_encoder.user_xattn_mode = "auto"
         model.graph_encoder.corpus_xattn_hint = {k: v for k, v in hint.items() if k != "user"}
         assert model.graph_encoder.resolved_xattn_mode("user") == "auto"    # the device decides; both variants are launched
-        got[4, "auto"] = util.score_rows(model, dc, 0, dc.rows, 1024)
+        lib.digat_set_staged_xattn(5)
+        got[5, "auto"] = util.score_rows(model, dc, 0, dc.rows, 1024)
     finally:
         lib.digat_set_staged_xattn(prev)
     assert torch.equal(plain, plain_per_row)
     for (mode, how), scores in got.items():
         assert torch.isfinite(scores).all(), (mode, how)
-        if mode != 4:
+        if mode < 4:
             assert torch.equal(scores, plain), (mode, how, float((scores - plain).abs().max()))
         else:       # a sequential channel sum instead of the lane tree: the last bits move (logits are O(100-1000) here)
             err = ((scores - plain).abs() / (1e-3 + plain.abs())).max().item()
-            assert err < 2e-5, (how, err)
-    assert torch.equal(got[4, "grouped"], got[4, "per row"]) and torch.equal(got[4, "grouped"], got[4, "every row"])
-    assert torch.equal(got[4, "grouped"], got[4, "auto"])
+            assert err < 2e-5, (mode, how, err)
+    for mode in (4, 5):
+        assert torch.equal(got[mode, "grouped"], got[mode, "per row"]) and torch.equal(got[mode, "grouped"], got[mode, "every row"])
+    assert torch.equal(got[5, "grouped"], got[5, "auto"])
 
 
 def test_encoder_call_is_graph_capturable():
