@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=1536, help="max rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
     ap.add_argument("--extra-steps", type=int, default=12, help="timed steps of each extra workload at N=1 (0 = skip)")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="--mode train: bf16 = bf16 matrix-core operands for the large training GEMMs (BASELINE configs[4])")
     ap.add_argument("--per-row-users", action="store_true",
                     help="expand the user tensors per row as the reference's driver does (default: once per impression)")
     ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1"],
@@ -296,6 +298,7 @@ def run_training(W, args, D: Dist, steps, warmup):
     from digat_amd.trainer import SyntheticTrainSet, Trainer
     cfg = W.cfg
     cfg.epoch, cfg.batch_size, cfg.lr, cfg.weight_decay, cfg.gradient_clip_norm = 1, 64, 1e-4, 0.0, 1.0
+    cfg.train_precision = args.train_precision
     ts = SyntheticTrainSet(W.corpus, 4, seed=D.rank)
     ts.negative_sampling()
     tr = Trainer(W.model, cfg, W.dc, ts, local_rank=(D.device_index if D.world > 1 else -1))
@@ -469,7 +472,7 @@ def cpu_baseline_and_auc(W, args, cpu_rows, cpu_seconds, report_baseline):
                  "max_abs_score_diff": float(np.max(np.abs(gpu_scores - cpu_scores))),
                  "gpu": [round(v, 6) for v in mg], "cpu": [round(v, 6) for v in mc], "rows": int(n_rows), "impressions": int(n_imps),
                  "metrics": ["AUC", "MRR", "nDCG@5", "nDCG@10"], "tolerance": 1e-4}
-    return baseline, auc_match
+    return baseline, auc_match, (cpu_scores, n_rows)
 
 
 def workload_config(W, args, D):
@@ -501,8 +504,9 @@ def main():
                 "metric": "DIGAT training rows/sec (DDP step: forward, backward, gradient all-reduce, clip, Adam)",
                 "value": rows / elapsed, "unit": "rows/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": W.wl["label"].replace("dev inference", "training"), "behaviours_per_rank_step": 64,
+                "dtype": "f32" if args.train_precision == "fp32" else "bf16 matrix-core operands, f32 master weights / accumulation",
+                "data": "synthetic",
+                "config": {"workload": W.wl["label"].replace("dev inference", "training").replace("fp32 ", ""), "behaviours_per_rank_step": 64,
                            "candidates_per_behaviour": 5, "rows_per_rank_step": 320, "dropout": W.wl["dropout"],
                            "parallelism": f"ddp{D.world} (DistributedDataParallel, RCCL all-reduce of the gradients)"},
                 "final_loss": run.loss}))
@@ -519,18 +523,37 @@ def main():
         return
 
     roof_dom, roof_x, kernel_ms, kernel_iso = rooflines(W, run, args)
-    cpu_baseline = auc_match = None
+    cpu_baseline = auc_match = cpu_sample = None
     if args.cpu_rows > 0:
         # N = 1: the reported CPU baseline (~20 s) and the AUC match on its rows; N > 1: a short AUC match only
         rows = args.cpu_rows if D.world == 1 else min(args.cpu_rows, 384)
         secs = args.cpu_seconds if D.world == 1 else min(args.cpu_seconds, 6.0)
-        cpu_baseline, auc_match = cpu_baseline_and_auc(W, args, rows, secs, report_baseline=D.world == 1)
+        cpu_baseline, auc_match, cpu_sample = cpu_baseline_and_auc(W, args, rows, secs, report_baseline=D.world == 1)
     matched = auc_match is not None and auc_match["max_abs_metric_diff"] <= auc_match["tolerance"]
 
     extra = None
     if D.world == 1 and args.extra_steps > 0 and args.workload == "auto":
         # BASELINE configs[2] and the configs[3] shape, a few steps each, in the same invocation (same method, fewer steps)
         extra = {}
+        if args.projection == "bf16x6" and cpu_sample is not None:
+            # BASELINE configs[4], inference half: the same workload with P', Q of Eq. 8 stored in bf16 (projection_mode
+            # "pq-bf16"); metric drift on the rows of the CPU sample against the fp32 oracle
+            from digat_amd import evaluate, util
+            W.model.graph_encoder.projection_mode = "pq-bf16"
+            r4 = run_inference(W, args, D, args.extra_steps, 3, with_profile=False)
+            cpu_scores, n_rows = cpu_sample
+            sc = util.score_rows(W.model, W.dc, 0, n_rows, args.batch).cpu().numpy()
+            lab, ri = W.corpus.row_label[:n_rows], W.corpus.row_impression[:n_rows]
+            mg = evaluate.scoring(lab, evaluate.impression_ranks(sc, ri), ri)
+            mc = evaluate.scoring(lab, evaluate.impression_ranks(cpu_scores, ri), ri)
+            extra["mind-small-default/pq-bf16"] = {
+                "value": (r4.rows_done / W.mean_cand) / r4.elapsed, "unit": "impressions/s", "rows_per_s": r4.rows_done / r4.elapsed,
+                "ms_per_step": r4.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps,
+                "dtype": "f32 with P', Q of Eq. 8 (user graph, layers >= 1) in bf16",
+                "max_abs_metric_diff_vs_fp32_oracle": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
+                "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
+                "rows_compared": int(n_rows)}
+            W.model.graph_encoder.projection_mode = args.projection
         for other in ("mind-small-stress", "mind-large-default"):
             W2 = build_workload(other, args, D, 4096)
             r2 = run_inference(W2, args, D, args.extra_steps, 3, with_profile=False)

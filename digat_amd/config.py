@@ -36,6 +36,8 @@ class Config:
         p.add_argument('--gradient_clip_norm', type=float, default=1)
         p.add_argument('--early_stopping_epoch', type=int, default=5)
         p.add_argument('--dev_criterion', default='avg', choices=['auc', 'mrr', 'ndcg5', 'ndcg10', 'avg'])
+        p.add_argument('--train_precision', default='fp32', choices=['fp32', 'bf16'],
+                       help='bf16: bf16 matrix-core operands for the large training GEMMs (fp32 master weights / accumulation)')
         p.add_argument('--dropout_rate', type=float, default=0.2)
         p.add_argument('--graph_depth', type=int, default=3)
         p.add_argument('--SAG_hops', type=int, default=2)

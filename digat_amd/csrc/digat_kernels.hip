@@ -257,6 +257,16 @@ int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream
     return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream);
 }
 
+// BASELINE configs[4], training half: the >= 2048-row GEMMs of the training path (projections, featureAffine, input
+// gradients) with ONE bf16 product per fp32 product — plain bf16 mixed precision: fp32 master weights and activations, bf16
+// matrix-core operands, fp32 accumulation — instead of the six of the fp32-grade split.  Weight gradients stay on the fp32 MFMA.
+static int g_train_bf16 = 0;
+int digat_set_train_precision(int bf16) {
+    const int prev = g_train_bf16;
+    g_train_bf16 = bf16 ? 1 : 0;
+    return prev;
+}
+
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
                        int M, int N, int K, void* wsplit, void* stream) {
     if (!x || !w || !y || !wsplit || M < 0 || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
@@ -265,6 +275,7 @@ int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float*
     if (rcs) return rcs;
     GemmArgs g = gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0);
     g.wsplit = (const unsigned short*)wsplit;
+    if (g_train_bf16) g.x1_segs = 7;
     if (M < 2048) return DIGAT_ERR_SHAPE;      // the bf16x6 kernel serves the big projections only
     return launch_gemm(g, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
@@ -733,7 +744,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             // caller says so (flags bit 3); there is no device-side decision for this graph
             rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit,
                             nullptr, nullptr, nullptr, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
-                            nullptr, pq_x3);
+                            nullptr, pq_x3, nullptr, 0,
+                            // the news graph's P' always carries K3 from the GEMM epilogue: bf16 storage applies at every layer
+                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0));
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;

@@ -83,6 +83,13 @@ class Trainer:
         else:
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.model = DDP(model, device_ids=[local_rank], output_device=local_rank)
+        # BASELINE configs[4]: --train_precision bf16 = bf16 matrix-core operands for the large training GEMMs (fp32 master
+        # weights, activations, accumulation and weight gradients); default fp32-grade
+        self.train_precision = getattr(config, "train_precision", "fp32")
+        if self.train_precision not in ("fp32", "bf16"):
+            raise ValueError("train_precision must be 'fp32' or 'bf16'")
+        from . import _lib
+        _lib.lib().digat_set_train_precision(1 if self.train_precision == "bf16" else 0)
         self.epochs = config.epoch
         self.batch_size = config.batch_size
         self.optimizer = optim.Adam(parameter_groups(self.model, getattr(config, "weight_decay", 0.0)), lr=config.lr)

@@ -136,8 +136,9 @@ enum { DIGAT_PROJ_PQ_X3 = 4 };
  * ones always take the wave-per-centre small-graph kernel).  SAG news graphs are breadth-first trees plus a few cross
  * edges: 3-4 entries per node at N = 26 or 65. */
 enum { DIGAT_NEWS_XATTN_SPARSE = 8 };
-/* digat_params.flags bit 4 (BASELINE configs[4]; folded inference path, bf16x6 projections, sparse Eq. 8 of the user graph,
- * layers >= 1 — the two launches that carry most of the bytes): the projection GEMM stores P' = K3 + K1 and Q = K2 in bf16
+/* digat_params.flags bit 4 (BASELINE configs[4]; folded inference path, bf16x6 projections, sparse Eq. 8: the user graph's
+ * layers >= 1 — the launches that carry most of the bytes — and news graphs of more than 16 nodes at every layer): the
+ * projection GEMM stores P' = K3 + K1 and Q = K2 in bf16
  * (round to nearest even) and the Eq. 8 kernel reads them as such; the score is still accumulated in fp32, h (the values), X
  * and every output stay fp32.  This is the reference's own "faster inference" idea — a quantised K3 + K1 + K2
  * (README.md:62-66).  Ranking metrics move by < 1e-4 (tests/test_hip_lowprec.py); element-wise the contexts move by ~1e-4.
@@ -315,6 +316,12 @@ int digat_xattn_pairwise_bwd(const float* dOut, const float* out, const float* X
                              int accumulate_da, int B, int n, int d, void* workspace, size_t workspace_bytes,
                              void* stream);
 int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* stream);          /* dr[b] = sum_j dP[b,j] */
+
+/* BASELINE configs[4], training half.  1: the >= 2048-row GEMMs of the training path (Eq. 8 projections, featureAffine,
+ * their input gradients) run with ONE bf16 product per fp32 product — bf16 mixed precision: fp32 master weights and
+ * activations, bf16 matrix-core operands, fp32 accumulation; 0 (default): the fp32-grade six-product split.  Weight gradients,
+ * the [B,d] linears and every reduction stay fp32.  Returns the previous setting. */
+int digat_set_train_precision(int bf16);
 
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
  * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one

@@ -104,6 +104,40 @@ def test_training_step_at_production_shapes_matches_reference_autograd():
         check_grad_digest(fx, name, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
 
 
+def test_bf16_training_precision_at_production_shapes():
+    """BASELINE configs[4], training half: digat_set_train_precision(1) — one bf16 product for the >= 2048-row GEMMs, fp32
+    master weights / accumulation / weight gradients.  Against the reference's fp32 autograd: loss within 1e-2 relative, every
+    gradient's norm within 5 % and its direction within 1 - cos < 5e-3 of this library's fp32-grade gradient; and the fp32-grade default must be restored bit for bit."""
+    from digat_amd import _lib
+    fx, enc, t, dims = build_default()
+    base_logits, base_loss, _, _ = run_step(enc, t, dims)
+    base_grads = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    prev = _lib.lib().digat_set_train_precision(1)
+    try:
+        fx, enc2, t2, dims = build_default()
+        logits, loss, Xn, ue = run_step(enc2, t2, dims)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().digat_set_train_precision(prev)
+    assert not torch.equal(logits, base_logits), "the bf16 path did not run"
+    assert abs(float(loss.detach()) - float(fx["out_loss"])) <= 1e-2 * abs(float(fx["out_loss"])) + 1e-4      # bf16: 2^-8 per product
+    close(logits, fx["out_logits"], "bf16 logits", rtol=2e-2, atol=2e-2 * float(np.abs(fx["out_logits"]).max()))
+    worst = 0.0
+    for name, p in enc2.named_parameters():
+        g = p.grad.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        ref_norm = float(fx["gn_" + name])
+        norm = float(np.sqrt((g ** 2).sum()))
+        assert abs(norm - ref_norm) <= 0.05 * ref_norm + 1e-9, (name, norm, ref_norm)
+        b = base_grads[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
+        cos = float((g * b).sum() / (np.linalg.norm(g) * np.linalg.norm(b) + 1e-30))
+        worst = max(worst, 1.0 - cos)
+        assert cos > 0.995, (name, cos)
+    print(f"\n[bf16 training] loss {float(loss.detach()):.6f} vs reference {float(fx['out_loss']):.6f}; worst 1 - cos(grad, fp32 grad) = {worst:.2e}")
+    fx, enc3, t3, dims = build_default()
+    logits3, _, _, _ = run_step(enc3, t3, dims)
+    assert torch.equal(logits3, base_logits)
+
+
 def test_training_gradients_are_reproducible():
     fx = load_golden("train_step.npz")
     grads = []
