@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collect the round's measurements on the GPU box (run through gpurun from the repository root):
+#   bash tools/collect_profiles.sh r02
+# Writes gpurun_out/<tag>/{bench.json, trace/, pmc_fetch/, pmc_write/, pmc_sq/ ...}; tools/summarize_profile.py then condenses
+# them into profiles/<tag>_final_*.  Counter passes are separate runs (--pmc never together with a trace: the pool refuses it).
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+B="python3 $ROOT/bench.py --extra-steps 0 --cpu-rows 0 --steps 30"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_traced.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_mfma -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_mfma.err
+# the LDS-staged pipelined Eq. 8 kernel (opt-in): its HBM traffic
+DIGAT_XATTN_STAGED=1 DIGAT_STAGED_CFG=4 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_stream -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fs.err
+DIGAT_XATTN_STAGED=1 DIGAT_STAGED_CFG=4 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_stream -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_ws.err
+cd $ROOT
+python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma --match gemm_bf16x6s > $OUT/gemm_pmc.txt 2>&1
+python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write --match xattn_sparse > $OUT/sparse_pmc.txt 2>&1
+python3 tools/pmc_table.py $OUT/pmc_fetch_stream $OUT/pmc_write_stream --match xattn_stream > $OUT/stream_pmc.txt 2>&1
+python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
+# keep what is merged back small: drop the raw per-dispatch tables
+find $OUT -name "*counter_collection.csv" -size +1M -delete
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+ls -la $OUT
