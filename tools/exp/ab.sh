@@ -1,7 +1,2 @@
-mkdir -p gpurun_out/r02t
-timeout 900 python -m pytest tests/test_hip_training.py tests/test_hip_lowprec.py -m gpu -x -q -s > gpurun_out/r02t/pytest.log 2>&1; grep -v "^$" gpurun_out/r02t/pytest.log | tail -n 12
-python bench.py --mode train --steps 20 > gpurun_out/r02t/train_fp32.json 2>/dev/null
-python bench.py --mode train --steps 20 --train-precision bf16 > gpurun_out/r02t/train_bf16.json 2>/dev/null
-python bench.py --workload mind-small-stress --extra-steps 0 --cpu-rows 0 --steps 12 --impressions 4096 > gpurun_out/r02t/stress_fp32.json 2>/dev/null
-python bench.py --workload mind-small-stress --extra-steps 0 --cpu-rows 0 --steps 12 --impressions 4096 --projection pq-bf16 > gpurun_out/r02t/stress_pq.json 2>/dev/null
-cat gpurun_out/r02t/train_fp32.json gpurun_out/r02t/train_bf16.json | cut -c1-400
+mkdir -p gpurun_out/r02w
+for p in 0 40000; do DIGAT_GEMM_DYNLDS=$p python bench.py --extra-steps 0 --cpu-rows 0 --steps 60 > gpurun_out/r02w/b_dyn${p}.json 2>gpurun_out/r02w/err$p.txt; done
