@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r02w
-for p in 0 40000; do DIGAT_GEMM_DYNLDS=$p python bench.py --extra-steps 0 --cpu-rows 0 --steps 60 > gpurun_out/r02w/b_dyn${p}.json 2>gpurun_out/r02w/err$p.txt; done
+mkdir -p gpurun_out/r02x
+for p in 0 1 0 1; do DIGAT_SPARSE_XCD=$p python bench.py --extra-steps 0 --cpu-rows 512 --cpu-seconds 6 --steps 40 > gpurun_out/r02x/b_xcd${p}_$RANDOM.json 2>/dev/null; done
