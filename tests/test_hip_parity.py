@@ -860,3 +860,29 @@ def test_a7_topic_pooling_standalone(B, H, C, d, kind):
     for b in range(B):
         empty[b, np.unique(idx[b])] = False
     assert (got[empty] == 0).all(), "empty segments must be exactly zero"
+
+
+def test_per_news_caches_follow_the_weights():
+    """c_n0 and the layer-0 tables of a DeviceCorpus belong to one weight version.  compute_scores must
+    rebuild them after the weights moved (an optimizer step, load_state_dict) — the scores then equal those of a fresh corpus."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=600, sag_neighbors=3, sag_hops=2, impressions=30, mean_candidates=20.0, max_candidates=50, seed=131)
+    corpus = synthetic.make_corpus(spec)
+    L = 2
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    sd1 = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=132, bias_std=0.05)
+    sd2 = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=133, bias_std=0.05)
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    s1, _ = util.compute_scores(model, dc, 512, labels=corpus.row_label)
+    key1 = dc.weights_key
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})      # in place: same storages, new versions
+    s2, _ = util.compute_scores(model, dc, 512, labels=corpus.row_label)
+    assert dc.weights_key != key1
+    fresh = util.DeviceCorpus.from_numpy(corpus, _dev())
+    s2_fresh, _ = util.compute_scores(model, fresh, 512, labels=corpus.row_label)
+    assert np.array_equal(s2, s2_fresh) and not np.allclose(s1, s2)
