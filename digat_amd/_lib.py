@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdigat_hip.so")
+# DIGAT_HIP_LIB: another build of the same ABI (A/B measurements of two kernel variants in one run)
+LIB_PATH = os.environ.get("DIGAT_HIP_LIB") or os.path.join(_HERE, "lib", "libdigat_hip.so")
 DIGAT_MAX_DEPTH = 16
 DIGAT_MAX_NODES = 128
 

@@ -122,4 +122,6 @@ class PrecomputedNewsEncoder(nn.Module):
     def forward(self, news_ids, _mask=None):
         if news_ids.dim() == 3 and news_ids.shape[2] == 1:
             news_ids = news_ids.squeeze(2)
-        return self.embed_table[news_ids.long()]
+        # F.embedding, not table[ids]: its backward is one dense-embedding kernel, where advanced indexing goes through
+        # index_put_(accumulate=True) — sort-based, 0.72 ms per call at the training shapes (1.45 of a 11.9 ms step)
+        return torch.nn.functional.embedding(news_ids.long(), self.embed_table)

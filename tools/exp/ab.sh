@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r02aa
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r02aa/pytest.log 2>&1; tail -n 6 gpurun_out/r02aa/pytest.log
+mkdir -p gpurun_out/r02ad
+for i in 1 2; do python tools/train_bench.py 2>/dev/null | tail -n 1; done
+timeout 600 python -m pytest tests/test_hip_training.py tests/test_hip_ddp.py -m gpu -x -q 2>&1 | tail -n 2
