@@ -74,6 +74,10 @@ _SIGNATURES = {
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
     "digat_gat_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_gat_fwd": (C.c_int, [_f] * 7 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_gat_train_save_bytes": (C.c_size_t, [C.c_int] * 3),
+    "digat_gat_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "digat_gat_fwd_train": (C.c_int, [_f] * 7 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
+    "digat_gat_bwd": (C.c_int, [_f] * 7 + [C.c_float, _f, C.c_size_t] + [_f] * 5 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_sag_cos_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "digat_sag_cos_topk": (C.c_int, [_f, _f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, _f, _f, _f, C.c_size_t, _f]),
     "digat_sag_news_graph": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float] + [_f] * 5),

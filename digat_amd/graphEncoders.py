@@ -443,7 +443,8 @@ class _Ablation(GraphEncoder):
     """Shared machinery.  A subclass names which graph runs Eq. 8 (``EQ8``), which runs the vanilla-GAT layer (``GAT``)
     and whether the news context exists (``NEWS_CONTEXT``); parameter names are the reference's, so its checkpoints
     load.  Inference / eval-mode forward run on the HIP kernels (``digat_xattn_fwd``, ``digat_gat_fwd``,
-    ``digat_news_ctx_fwd``, ``digat_user_ctx_fwd``); training these variants is not implemented natively."""
+    ``digat_news_ctx_fwd``, ``digat_user_ctx_fwd``); training-mode forward (with autograd) goes through
+    ``training.ablation_forward_train`` on the ``digat_*_fwd_train`` / ``digat_*_bwd`` pairs."""
     EQ8: tuple = ()
     GAT: tuple = ()
     NEWS_CONTEXT = True
@@ -552,7 +553,10 @@ class _Ablation(GraphEncoder):
 
     def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                 user_category_mask, user_category_indices):
-        self._eval_only(type(self).__name__ + ".forward")
+        if self.training and torch.is_grad_enabled():
+            from .training import ablation_forward_train
+            return ablation_forward_train(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
+                                          user_graph, user_category_mask, user_category_indices)
         c_n = self.compute_news_graph_context(news_graph_embeddings, news_graph_mask)
         return self._encode(_lib.f32(news_graph_embeddings), news_graph, news_graph_mask, user_news_embedding, user_graph,
                             user_category_mask, user_category_indices, c_n)
@@ -579,6 +583,10 @@ class wo_SA(_Ablation):
 
     def forward(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                 user_category_mask, user_category_indices):
+        if self.training and torch.is_grad_enabled():
+            from .training import ablation_forward_train
+            return ablation_forward_train(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
+                                          user_graph, user_category_mask, user_category_indices)
         return self._run(news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices)
 
     def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,

@@ -374,6 +374,42 @@ class XattnFused(Function):
         return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None
 
 
+class GatFused(Function):
+    """Vanilla-GAT update layer of the ablation encoders on already-dropped-out inputs (graphEncoders.py:493-503):
+    ``digat_gat_fwd_train`` / ``digat_gat_bwd``."""
+
+    @staticmethod
+    def forward(ctx, Xd, A, W, bW, a1, a2, p_alpha):
+        Xd = _f(Xd)
+        B, n, d = Xd.shape
+        dev = Xd.device
+        out = torch.empty_like(Xd)
+        nsave, nws = L().digat_gat_train_save_bytes(B, n, d), L().digat_gat_train_workspace_bytes(B, n, d)
+        save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
+        p = float(p_alpha)
+        _lib.check(L().digat_gat_fwd_train(Xd.data_ptr(), A.data_ptr(), W.data_ptr(), bW.data_ptr(), a1.data_ptr(), a2.data_ptr(),
+                                           out.data_ptr(), p, _seed() if p > 0 else 0, B, n, d, save.data_ptr(), nsave,
+                                           ws.data_ptr(), nws, S()), "digat_gat_fwd_train")
+        ctx.save_for_backward(Xd, A, W, a1, a2, out, save)
+        ctx.p, ctx.sizes = p, (nsave, nws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        Xd, A, W, a1, a2, out, save = ctx.saved_tensors
+        B, n, d = Xd.shape
+        dev = Xd.device
+        dOut = _f(dOut)
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dX, dW = torch.empty_like(Xd), torch.empty_like(W)
+        dbW, da1, da2 = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+        _lib.check(L().digat_gat_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), A.data_ptr(), W.data_ptr(), a1.data_ptr(),
+                                     a2.data_ptr(), ctx.p, save.data_ptr(), nsave, dX.data_ptr(), dW.data_ptr(), dbW.data_ptr(),
+                                     da1.data_ptr(), da2.data_ptr(), B, n, d, ws.data_ptr(), nws, S()), "digat_gat_bwd")
+        return dX, None, dW, dbW, da1.view_as(a1), da2.view_as(a2), None
+
+
 class NewsCtxFused(Function):
     """compute_news_graph_context (graphEncoders.py:109-114), training mode."""
 
@@ -477,9 +513,16 @@ def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True):
                             getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0)
 
 
-def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
-                        user_category_mask, user_category_indices):
-    """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24)."""
+def gat_embeddings(enc, g, i, X, A_bytes, p, training=True):
+    """Vanilla-GAT update layer (graphEncoders.py:493-503 / :509-519), training mode."""
+    Xd = dropout(X, p / 2, training)
+    W = getattr(enc, f"{g}_graph_attention_W")[i]
+    return GatFused.apply(Xd, A_bytes, W.weight, W.bias, getattr(enc, f"{g}_graph_attention_a1")[i].weight,
+                          getattr(enc, f"{g}_graph_attention_a2")[i].weight, p if training else 0.0)
+
+
+def _train_inputs(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph, user_category_mask,
+                  user_category_indices):
     p = enc.dropout_rate
     Xn = _lib.f32(news_graph_embeddings)
     ue = _lib.f32(user_news_embedding)
@@ -487,9 +530,44 @@ def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask,
     An, Mn = _lib.as_bytes(news_graph), _lib.as_bytes(news_graph_mask)
     Au, cm = _lib.as_bytes(user_graph), _lib.as_bytes(user_category_mask)
     ci = user_category_indices.to(torch.int64).contiguous()
-    B = Xn.shape[0]
-    topic = dropout(enc.topic_node_embedding.unsqueeze(0).expand(B, -1, -1), p / 2)
-    Xu = torch.cat([ue, topic], dim=1)
+    topic = dropout(enc.topic_node_embedding.unsqueeze(0).expand(Xn.shape[0], -1, -1), p / 2)
+    return p, Xn, An, Mn, torch.cat([ue, topic], dim=1), Au, cm, ci
+
+
+def ablation_forward_train(enc, *inputs):
+    """Training-mode forward of the five ablation encoders (graphEncoders.py:264-271 wo_SA, :374-382 Seq_SA, :523-535
+    wo_interaction, :672-683 News_graph_wo_inter, :817-829 User_graph_wo_inter), dropout placed as in the reference: p/2 on
+    every layer input, the topic nodes and the news-context gate; p on every alpha and the pooled topics."""
+    p, Xn, An, Mn, Xu, Au, cm, ci = _train_inputs(enc, *inputs)
+    kind = type(enc).__name__
+
+    def layer(g, i, X, A, cvec):
+        return graph_embeddings(enc, g, i, X, A, cvec, p) if g in enc.EQ8 else gat_embeddings(enc, g, i, X, A, p)
+
+    if kind == "wo_SA":
+        c = Xn[:, 0].contiguous()
+        for i in range(enc.graph_depth):
+            Xu = layer("user", i, Xu, Au, c)
+        return c, user_graph_context(enc, Xu, cm, ci, c, p)
+    c_n = news_graph_context(enc, Xn, Mn, p)
+    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p)
+    for i in range(enc.graph_depth):
+        if kind == "Seq_SA":                      # the news side is a sequence: pooled once, never updated
+            Xu = layer("user", i, Xu, Au, c_n)
+        else:
+            Xn_next = layer("news", i, Xn, An, c_u)
+            Xu = layer("user", i, Xu, Au, c_n)
+            Xn = Xn_next
+            c_n = c_n + news_graph_context(enc, Xn, Mn, p)
+        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p)
+    return c_n, c_u
+
+
+def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
+                        user_category_mask, user_category_indices):
+    """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24)."""
+    p, Xn, An, Mn, Xu, Au, cm, ci = _train_inputs(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
+                                                  user_graph, user_category_mask, user_category_indices)
     c_n = news_graph_context(enc, Xn, Mn, p)
     c_u = user_graph_context(enc, Xu, cm, ci, c_n, p)
     for i in range(enc.graph_depth):

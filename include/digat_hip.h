@@ -382,6 +382,18 @@ int digat_rank_metrics(const float* scores, const uint8_t* labels, const int64_t
 size_t digat_gat_workspace_bytes(int B, int n, int d);
 int digat_gat_fwd(const float* X, const uint8_t* A, const float* W, const float* bW, const float* a1, const float* a2,
                   float* out, int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
+/* The same layer in training mode (dropout live: graphEncoders.py:495 on the input is the caller's, :500 on alpha is
+ * p_alpha here), one call per direction like digat_xattn_fwd_train / digat_xattn_bwd: `save` carries h, alpha, the scores
+ * before leaky_relu and the dropout mask from the forward to the backward.  dX, dW, dbW, da1, da2 are written, not
+ * accumulated; sums run in index order (bit-reproducible). */
+size_t digat_gat_train_save_bytes(int B, int n, int d);
+size_t digat_gat_train_workspace_bytes(int B, int n, int d);
+int digat_gat_fwd_train(const float* X, const uint8_t* A, const float* W, const float* bW, const float* a1, const float* a2, float* out,
+                        float p_alpha, uint32_t seed, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int digat_gat_bwd(const float* dOut, const float* out, const float* X, const uint8_t* A, const float* W, const float* a1, const float* a2,
+                  float p_alpha, const void* save, size_t save_bytes, float* dX, float* dW, float* dbW, float* da1, float* da2,
+                  int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- semantic-augmented-graph construction: construct_SAG.py ------------------------------------
  * generate_cos_similarities (construct_SAG.py:112-162), one category: title/content [n, dim], corpus_title/corpus_content

@@ -404,6 +404,46 @@ def fixture_ablations(ge):
                  out_inference_news=inn.numpy(), out_inference_user=inu.numpy(), **extra)
 
 
+def fixture_ablation_train(ge):
+    """SURVEY §8f-3, training: one training step (dropout 0, loss of trainer.py:100) of each of the five ablation encoders
+    from the reference's autograd.  Tiny shapes with every gradient stored whole; wo_interaction (vanilla GAT on both graphs)
+    also at the production shapes with parameter gradients as digests.  Inputs and weights regenerate from seeds."""
+    cases = [(name, "tiny", (3, 4, 4, 10, 5, 32, 2, 85)) for name in
+             ("wo_SA", "Seq_SA", "wo_interaction", "News_graph_wo_inter", "User_graph_wo_inter")]
+    cases.append(("wo_interaction", "default", (8, 5, 10, 50, 17, 400, 3, 87)))
+    for name, tag, (B, K, N, H, C, d, L, seed) in cases:
+        state = synthetic.make_ablation_state_dict(name, d, C, L, seed=seed)
+        flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=seed + 1, isolated_news_rows=(2,))
+        users = synthetic.make_encoder_batch(B, N, H, C, d, seed=seed + 2, empty_history_rows=(1,))
+        cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C, graph_depth=L, dropout_rate=0.0)
+        enc = getattr(ge, name)(cfg, d)
+        enc.initialize()
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        enc.train()
+        Xn = T(flat["news_graph_embeddings"]).requires_grad_(True)
+        ue = T(users["user_news_embedding"]).requires_grad_(True)
+
+        def expand(t):                                                          # model.py:64-71
+            return t.unsqueeze(1).expand(B, K, *t.shape[1:]).contiguous().view(B * K, *t.shape[1:])
+
+        n, u = enc(Xn, T(flat["news_graph"]), T(flat["news_graph_mask"]), expand(ue), expand(T(users["user_graph"])),
+                   expand(T(users["user_category_mask"])), expand(T(users["user_category_indices"])))
+        logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+        loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+        loss.backward()
+        grads = {}
+        for k, v in enc.named_parameters():
+            if tag == "tiny":
+                grads["g_" + k] = v.grad.numpy()
+            else:
+                grads.update(grad_digest(k, v.grad.numpy()))
+        both = dict(flat)
+        both.update({"u_" + k: v for k, v in users.items()})
+        save(f"ablation_train_{name}_{tag}.npz", meta=np.array([B, K, N, H, C, d, L]), seeds=np.array([seed, seed + 1, seed + 2]),
+             input_checksum=checksum(both, state), out_logits=logits.detach().numpy(), out_loss=loss.detach().numpy(),
+             g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
+
+
 def fixture_msa():
     """MSA news encoder: the reference's own layers.MultiHeadAttention / layers.Attention modules composed
     as newsEncoders.MSA.forward composes them (newsEncoders.py:70-82; NewsEncoder.__init__ itself needs the dataset's
@@ -489,7 +529,8 @@ def main():
     print("reference imported from", REFERENCE)
     jobs = {"tiny": lambda: fixture_tiny(ge), "edges": lambda: fixture_edges(ge), "train_step": lambda: fixture_train_step(ge),
             "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev),
-            "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge), "msa": fixture_msa,
+            "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge),
+            "ablation_train": lambda: fixture_ablation_train(ge), "msa": fixture_msa,
             "sag": fixture_sag, "devset_2k": lambda: fixture_devset_2k(ge, ev)}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]        # python oracle/make_golden.py [name ...]
     for name in (only or list(jobs)):

@@ -85,6 +85,24 @@ def regenerate_train(fx):
     return (B, K, N, H, C, d, L), state, flat, users
 
 
+def regenerate_ablation_train(fx, name):
+    """Inputs and weights of ablation_train_<name>_<tag>.npz: (meta, state, per-row news batch, per-impression user batch)."""
+    from digat_amd import synthetic
+    B, K, N, H, C, d, L = (int(v) for v in fx["meta"])
+    s_w, s_n, s_u = (int(v) for v in fx["seeds"])
+    state = synthetic.make_ablation_state_dict(name, d, C, L, seed=s_w)
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=s_n, isolated_news_rows=(2,))
+    users = synthetic.make_encoder_batch(B, N, H, C, d, seed=s_u, empty_history_rows=(1,))
+    both = dict(flat)
+    both.update({"u_" + k: v for k, v in users.items()})
+    tot = 0.0
+    for v in list(both.values()) + list(state.values()):
+        tot += float(np.asarray(v, dtype=np.float64).sum())
+    assert abs(tot - float(fx["input_checksum"])) <= 1e-6 * max(1.0, abs(tot)), \
+        "synthetic generator drifted from the one that minted the fixture"
+    return (B, K, N, H, C, d, L), state, flat, users
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

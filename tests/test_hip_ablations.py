@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import check_grad_digest, load_golden, regenerate_ablation_train
 from oracle import digat_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -56,3 +56,76 @@ def test_model_selects_every_graph_encoder():
     cfg.graph_encoder = "nope"
     with pytest.raises(Exception, match="nope is not implemented"):
         Model(cfg, news_encoder=PrecomputedNewsEncoder(table))
+
+
+# ---- training (digat_gat_fwd_train / digat_gat_bwd and the Eq. 8 / context pairs through training.ablation_forward_train) ----
+def _train_case(name, tag, dropout=0.0):
+    from digat_amd import graphEncoders
+    fx = load_golden(f"ablation_train_{name}_{tag}.npz")
+    dims, w, flat, users = regenerate_ablation_train(fx, name)
+    B, K, N, H, C, d, L = dims
+    cfg = types.SimpleNamespace(news_graph_size=N, max_history_num=H, category_num=C, graph_depth=L, dropout_rate=dropout)
+    enc = getattr(graphEncoders, name)(cfg, d)
+    enc.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}, strict=True)
+    enc = enc.to(_dev()).train()
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(_dev()) for k, v in flat.items() if k.startswith("news_")}
+    t.update({k: torch.from_numpy(np.ascontiguousarray(v)).to(_dev()) for k, v in users.items() if k.startswith("user_")})
+    return fx, enc, t, dims
+
+
+def _train_step(enc, t, dims):
+    B, K, N, H, C, d, L = dims
+    Xn = t["news_graph_embeddings"].clone().requires_grad_(True)
+    ue = t["user_news_embedding"].clone().requires_grad_(True)
+
+    def expand(x):                                                   # model.py:64-71
+        return x.unsqueeze(1).expand(B, K, *x.shape[1:]).contiguous().view(B * K, *x.shape[1:])
+
+    n, u = enc(Xn, t["news_graph"], t["news_graph_mask"], expand(ue), expand(t["user_graph"]),
+               expand(t["user_category_mask"]), expand(t["user_category_indices"]))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()    # trainer.py:100
+    loss.backward()
+    torch.cuda.synchronize()
+    return logits, loss, Xn, ue
+
+
+def _close(got, want, what, rtol=2e-4, atol=2e-6):
+    got, want = got.detach().cpu().numpy(), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite"
+    scale = max(float(np.abs(want).max()), 1e-12)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.maximum(np.abs(want), 0.05 * scale)
+    assert not (err > tol).any(), f"{what}: max|diff| {err.max():.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("name,tag", [(n, "tiny") for n in O.ABLATIONS] + [("wo_interaction", "default")])
+def test_ablation_training_step_matches_reference_autograd(name, tag):
+    """Loss, logits and every gradient of one training step (dropout 0) against the reference's autograd.  Tolerance as
+    tests/test_hip_training.py: fp32 sums in a different order than ATen's -> 2e-4 relative + 2e-6 absolute."""
+    fx, enc, t, dims = _train_case(name, tag)
+    logits, loss, Xn, ue = _train_step(enc, t, dims)
+    _close(logits, fx["out_logits"], "logits", rtol=2e-5, atol=2e-5)
+    _close(loss, fx["out_loss"], "loss", rtol=1e-5, atol=1e-6)
+    _close(Xn.grad, fx["g_in_news_graph_embeddings"], "d news_graph_embeddings")
+    _close(ue.grad, fx["g_in_user_news_embedding"], "d user_news_embedding")
+    for k, p in enc.named_parameters():
+        assert p.grad is not None, k
+        if tag == "tiny":
+            _close(p.grad, fx["g_" + k], "grad " + k)
+        else:
+            check_grad_digest(fx, k, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
+
+
+def test_ablation_training_with_dropout_runs_and_is_reproducible():
+    """Dropout live (p = 0.2): finite loss and gradients, and the same seed gives the same bits twice."""
+    def once():
+        torch.manual_seed(5)
+        fx, enc, t, dims = _train_case("wo_interaction", "default", dropout=0.2)
+        logits, loss, Xn, ue = _train_step(enc, t, dims)
+        return loss.detach().clone(), Xn.grad.clone(), [p.grad.clone() for p in enc.parameters()]
+    l1, x1, g1 = once()
+    l2, x2, g2 = once()
+    assert torch.isfinite(l1) and torch.isfinite(x1).all() and all(torch.isfinite(g).all() for g in g1)
+    assert torch.equal(l1, l2) and torch.equal(x1, x2) and all(torch.equal(a, b) for a, b in zip(g1, g2))

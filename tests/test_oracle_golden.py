@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_grad_digest, load_golden, regenerate, regenerate_train, split_fixture
+from conftest import check_grad_digest, load_golden, regenerate, regenerate_ablation_train, regenerate_train, split_fixture
 from oracle import digat_oracle as O
 
 RTOL, ATOL = 1e-5, 1e-5
@@ -273,3 +273,37 @@ def test_oracle_on_a_slice_of_the_2k_devset():
                            torch.from_numpy(corpus.user_category_indices).index_select(0, imp), sa, graphs, masks, c_n0).numpy()
     want = fx["scores"][:rows]
     assert np.allclose(got, want, rtol=2e-5, atol=1e-4), np.abs(got - want).max()
+
+
+ABLATION_TRAIN = [(n, "tiny") for n in O.ABLATIONS] + [("wo_interaction", "default")]
+
+
+@pytest.mark.parametrize("name,tag", ABLATION_TRAIN)
+def test_ablation_train_step_matches_reference_autograd(name, tag):
+    """One training step (dropout 0) of every ablation encoder: the oracle's autograd against the reference's
+    (ablation_train_*.npz; tiny shapes with whole gradients, wo_interaction also at N=10, U=67, d=400 with digests)."""
+    fx = load_golden(f"ablation_train_{name}_{tag}.npz")
+    (B, K, N, H, C, d, L), w, flat, users = regenerate_ablation_train(fx, name)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.as_params(w).items()}
+    Xn = torch.from_numpy(flat["news_graph_embeddings"]).clone().requires_grad_(True)
+    ue = torch.from_numpy(users["user_news_embedding"]).clone().requires_grad_(True)
+
+    def expand(t):
+        t = torch.from_numpy(t) if isinstance(t, np.ndarray) else t
+        return t.unsqueeze(1).expand(B, K, *t.shape[1:]).reshape(B * K, *t.shape[1:])
+
+    n, u = O.ablation_encode(name, p, L, Xn, torch.from_numpy(flat["news_graph"]), torch.from_numpy(flat["news_graph_mask"]),
+                             expand(ue), expand(users["user_graph"]), expand(users["user_category_mask"]),
+                             expand(users["user_category_indices"]))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = O.training_loss(logits)
+    loss.backward()
+    close(logits.detach().numpy(), fx["out_logits"], "logits")
+    close(loss.detach().numpy(), fx["out_loss"], "loss")
+    close(Xn.grad.numpy(), fx["g_in_news_graph_embeddings"], "dX_news")
+    close(ue.grad.numpy(), fx["g_in_user_news_embedding"], "dX_user")
+    for k, v in p.items():
+        if tag == "tiny":
+            close(v.grad.numpy(), fx["g_" + k], "grad " + k)
+        else:
+            check_grad_digest(fx, k, v.grad.numpy(), 2e-5, "grad ")
