@@ -85,6 +85,15 @@ _SIGNATURES = {
     "digat_split_msa_weights": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f, _f]),
     "digat_msa_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_msa_fwd": (C.c_int, [C.POINTER(MsaParams), _f, _f, _f, C.c_int, C.c_int, _f, C.c_size_t, _f]),
+    "digat_msa_train_save_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_msa_train_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_msa_fwd_train": (C.c_int, [C.POINTER(MsaParams), _f, _f, _f, C.c_float, C.c_uint32, C.c_int, C.c_int, _f, C.c_size_t, _f,
+                                      C.c_size_t, _f]),
+    "digat_msa_bwd": (C.c_int, [C.POINTER(MsaParams), _f, _f, _f, C.c_float, _f, C.c_size_t, _f, C.c_int64] + [_f] * 8
+                      + [C.c_int, C.c_int, _f, C.c_size_t, _f]),
+    "digat_msa_row_grad_ld": (C.c_int64, [C.c_int] * 3),
+    "digat_embedding_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "digat_embedding_bwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, _f, _f, C.c_size_t, _f]),
     "digat_encoder_grouped_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd_grouped": (C.c_int, [C.POINTER(Params)] + [_f] * 11 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_encoder_fwd_grouped_cached": (C.c_int, [C.POINTER(Params)] + [_f] * 14 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),

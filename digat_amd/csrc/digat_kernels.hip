@@ -1092,5 +1092,6 @@ int digat_row_logits(const float* news_ctx, const float* user_ctx, float* logits
 #include "digat_train_abi.inc"
 #include "digat_eval.inc"
 #include "digat_news.inc"
+#include "digat_news_train.inc"
 #include "digat_gat.inc"
 #include "digat_sag.inc"

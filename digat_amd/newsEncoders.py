@@ -1,5 +1,6 @@
-"""News encoders: UPSTREAM of the hot path.  Stock PyTorch-ROCm modules for training; ``MSA`` in eval mode runs on
-the HIP kernels of ``csrc/digat_news.inc`` (``digat_msa_fwd``).
+"""News encoders: UPSTREAM of the hot path.  ``MSA`` on the GPU runs on the HIP kernels: inference on
+``digat_msa_fwd`` (``csrc/digat_news.inc``), training forward / backward on ``digat_msa_fwd_train`` / ``digat_msa_bwd``
+(``csrc/digat_news_train.inc``); on the CPU (tests without a GPU) and for ``CNN`` the stock PyTorch modules below.
 
 Their output ``[., news_embedding_dim]`` is the graph encoder's input.  They are restated here
 so that ``Model.forward`` (training) and the news-representation cache of ``compute_scores``
@@ -72,6 +73,77 @@ class _Conv(nn.Module):
         return F.relu(self.conv(x))
 
 
+class MsaFused(torch.autograd.Function):
+    """The MSA news encoder as one library call per direction (``digat_msa_fwd_train`` / ``digat_msa_bwd``,
+    ``digat_embedding_bwd`` for the word-embedding rows)."""
+
+    @staticmethod
+    def _params(table, WQ, bQ, WK, WV, bV, A1, b1, a2, heads, dk):
+        from . import _lib
+        P = _lib.MsaParams(word_embedding_dim=table.shape[1], head_num=heads, head_dim=dk, attention_dim=A1.shape[0])
+        for name, w in zip(("word_embedding", "W_Q", "b_Q", "W_K", "W_V", "b_V", "A1", "b1", "a2"), (table, WQ, bQ, WK, WV, bV, A1, b1, a2)):
+            setattr(P, name, w.data_ptr())
+        return P
+
+    @staticmethod
+    def forward(ctx, tokens, mask, table, WQ, bQ, WK, WV, bV, A1, b1, a2, heads, dk, p_drop):
+        from . import _lib
+        L = _lib.lib()
+        ws_ = [w.detach().float().contiguous() for w in (table, WQ, bQ, WK, WV, bV, A1, b1, a2)]
+        dev = _lib.require_device(tokens, mask, *ws_)
+        T, Lw = tokens.shape
+        dm, att = ws_[0].shape[1], ws_[6].shape[0]
+        P = MsaFused._params(*ws_, heads, dk)
+        out = torch.empty((T, heads * dk), dtype=torch.float32, device=dev)
+        nsave = L.digat_msa_train_save_bytes(T, Lw, dm, heads, dk, att)
+        nws = L.digat_msa_train_workspace_bytes(T, Lw, dm, heads, dk, att)
+        save = torch.empty(max(int(nsave), 256), dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(nws, dev, "msa_train")
+        p = float(p_drop)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+        _lib.check(L.digat_msa_fwd_train(P, tokens.data_ptr(), mask.data_ptr(), out.data_ptr(), p, seed, T, Lw, save.data_ptr(), nsave,
+                                         ws.data_ptr(), nws, _lib.stream_ptr()), "digat_msa_fwd_train")
+        ctx.save_for_backward(tokens, mask, save, *ws_)
+        ctx.dims, ctx.p, ctx.sizes = (heads, dk), p, (nsave, nws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib
+        L = _lib.lib()
+        tokens, mask, save, *ws_ = ctx.saved_tensors
+        table, WQ, bQ, WK, WV, bV, A1, b1, a2 = ws_
+        heads, dk = ctx.dims
+        T, Lw = tokens.shape
+        dm, hd, att = table.shape[1], heads * dk, A1.shape[0]
+        dev = tokens.device
+        dout = dout.float().contiguous()
+        P = MsaFused._params(*ws_, heads, dk)
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "msa_train")
+        f = dict(dtype=torch.float32, device=dev)
+        ld = int(L.digat_msa_row_grad_ld(T, Lw, dm))
+        row_grad = torch.empty((T * Lw, ld), **f)
+        dWQ, dWK, dWV = (torch.empty((hd, dm), **f) for _ in range(3))
+        dbQ, dbV = torch.empty(hd, **f), torch.empty(hd, **f)
+        dA1, db1, da2 = torch.empty((att, hd), **f), torch.empty(att, **f), torch.empty(att, **f)
+        _lib.check(L.digat_msa_bwd(P, tokens.data_ptr(), mask.data_ptr(), dout.data_ptr(), ctx.p, save.data_ptr(), nsave,
+                                   row_grad.data_ptr(), ld, dWQ.data_ptr(), dbQ.data_ptr(), dWK.data_ptr(), dWV.data_ptr(), dbV.data_ptr(),
+                                   dA1.data_ptr(), db1.data_ptr(), da2.data_ptr(), T, Lw, ws.data_ptr(), nws, _lib.stream_ptr()),
+                   "digat_msa_bwd")
+        dtable = None
+        if ctx.needs_input_grad[2]:
+            # index plumbing only: the rows in token order (stable); the sums run in the library, in that fixed order
+            stok, order = torch.sort(tokens.reshape(-1).to(torch.int64), stable=True)
+            stok, order = stok.to(torch.int32), order.to(torch.int32)
+            dtable = torch.zeros_like(table)
+            nb = L.digat_embedding_bwd_workspace_bytes(T * Lw, dm)
+            ews = _lib.workspace(nb, dev, "emb_bwd")
+            _lib.check(L.digat_embedding_bwd(row_grad.data_ptr(), ld, order.data_ptr(), stok.data_ptr(), T * Lw, dm, dtable.data_ptr(),
+                                             ews.data_ptr(), nb, _lib.stream_ptr()), "digat_embedding_bwd")
+        return None, None, dtable, dWQ, dbQ, dWK, dWV, dbV, dA1, db1, da2.view_as(a2), None, None, None
+
+
 class NewsEncoder(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -104,13 +176,32 @@ class MSA(NewsEncoder):
         self.attention.initialize()
 
     def forward(self, title_text, title_mask):
-        if not self.training and not torch.is_grad_enabled() and title_text.is_cuda:
-            return self.encode_hip(title_text, title_mask)      # inference: the HIP kernels (digat_msa_fwd)
+        if title_text.is_cuda and not torch.is_grad_enabled():
+            if not self.training or self.dropout.p == 0:
+                return self.encode_hip(title_text, title_mask)  # inference: the HIP kernels (digat_msa_fwd)
+        if title_text.is_cuda and torch.is_grad_enabled() and title_text.shape[-1] <= 32:
+            return self.train_hip(title_text, title_mask)       # training: digat_msa_fwd_train / digat_msa_bwd
+        return self.forward_stock(title_text, title_mask)       # CPU (tests without a GPU)
+
+    def forward_stock(self, title_text, title_mask):
+        """The same function on stock PyTorch modules (CPU runs; the yardstick of tools/kbench.py msa-train)."""
         w, B, n = self._words(title_text)
         h = F.relu(self.multiheadSelfattention(w))
         return self.attention(h, mask=title_mask.view(B * n, -1)).view(B, n, self.news_embedding_dim)
 
-    # ---- inference on the HIP kernels (digat_news.inc); training stays on the stock modules above
+    def train_hip(self, title_text, title_mask):
+        """Forward with autograd through the HIP pair (newsEncoders.py:70-82; dropout on the embedded tokens in train mode)."""
+        shape = title_text.shape
+        Lw = shape[-1]
+        mha, att = self.multiheadSelfattention, self.attention
+        out = MsaFused.apply(title_text.reshape(-1, Lw).to(torch.int32).contiguous(),
+                             (title_mask.reshape(-1, Lw) != 0).to(torch.uint8).contiguous(),
+                             self.word_embedding.weight, mha.W_Q.weight, mha.W_Q.bias, mha.W_K.weight, mha.W_V.weight, mha.W_V.bias,
+                             att.affine1.weight, att.affine1.bias, att.affine2.weight, mha.h, mha.d_k,
+                             float(self.dropout.p) if self.training else 0.0)
+        return out.view(*shape[:-1], self.news_embedding_dim)
+
+    # ---- inference on the HIP kernels (digat_news.inc)
     def _hip_params(self):
         from . import _lib
         ws = [self.word_embedding.weight, self.multiheadSelfattention.W_Q.weight, self.multiheadSelfattention.W_Q.bias,

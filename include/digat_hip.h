@@ -434,6 +434,28 @@ int digat_split_msa_weights(const float* W_Q, const float* W_K, const float* W_V
 size_t digat_msa_workspace_bytes(int T, int Lw, int word_embedding_dim, int head_num, int head_dim, int attention_dim);
 int digat_msa_fwd(const digat_msa_params* params, const int32_t* title_text, const uint8_t* title_mask, float* out,
                   int T, int Lw, void* workspace, size_t workspace_bytes, void* stream);
+/* The same encoder in training mode (newsEncoders.py:70-82 with dropout live), one call per direction.  p_drop is the dropout
+ * on the embedded tokens (:77).  `save` carries the dropped embeddings, Q|K|V, h, the affine1 product and the pooling weights to the
+ * backward; the attention scores are recomputed there.  The *_wsplit fields of params are ignored (the weights change every
+ * optimiser step: they are split inside, into the workspace).  Lw <= 32, attention_dim % 4 == 0.
+ * digat_msa_bwd writes (does not accumulate) row_grad [T*Lw, word_embedding_dim], rows ld_row_grad floats apart
+ * (word_embedding_dim, or digat_msa_row_grad_ld(): padded to a multiple of 80 so that one matrix-core product computes it) — the
+ * gradient at the embedding rows the tokens looked up — and dW_Q dW_K dW_V [hd, word_embedding_dim], db_Q db_V [hd], dA1 [attention_dim, hd], db1 da2 [attention_dim].
+ * digat_embedding_bwd sums row_grad per token into table_grad [V, word_embedding_dim] (zero-filled by the caller) in a fixed
+ * order — bit-reproducible, no atomics: `order` [M] = the row indices stably sorted by token, sorted_tokens [M] the tokens in that order. */
+size_t digat_msa_train_save_bytes(int T, int Lw, int word_embedding_dim, int head_num, int head_dim, int attention_dim);
+size_t digat_msa_train_workspace_bytes(int T, int Lw, int word_embedding_dim, int head_num, int head_dim, int attention_dim);
+int digat_msa_fwd_train(const digat_msa_params* params, const int32_t* title_text, const uint8_t* title_mask, float* out, float p_drop,
+                        uint32_t seed, int T, int Lw, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int digat_msa_bwd(const digat_msa_params* params, const int32_t* title_text, const uint8_t* title_mask, const float* dout, float p_drop,
+                  const void* save, size_t save_bytes, float* row_grad, int64_t ld_row_grad, float* dW_Q, float* db_Q, float* dW_K,
+                  float* dW_V, float* db_V, float* dA1, float* db1, float* da2, int T, int Lw, void* workspace, size_t workspace_bytes,
+                  void* stream);
+int64_t digat_msa_row_grad_ld(int T, int Lw, int word_embedding_dim);
+size_t digat_embedding_bwd_workspace_bytes(int64_t M, int dm);
+int digat_embedding_bwd(const float* row_grad, int64_t ld_row_grad, const int32_t* order, const int32_t* sorted_tokens, int64_t M, int dm,
+                        float* table_grad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
  * Between start and stop every kernel launch of this library is bracketed by two events recorded

@@ -468,6 +468,43 @@ def fixture_msa():
              input_checksum=checksum({"t": text, "m": mask}, state), out_news_representation=out.numpy(), **extra)
 
 
+def fixture_msa_train():
+    """MSA news encoder, training: the same module composition as fixture_msa, train mode with dropout 0, loss =
+    sum(out * R) for a seeded random R, gradients of every parameter including the word embedding from the reference's autograd.
+    Tiny shapes with whole gradients; the default shapes (16 heads x 25, 300-d words, 32 tokens; 72 titles = 2 304 token rows, so
+    the >= 2048-row matrix-core paths are taken) with digests.  One title is all padding (its pooling is uniform, layers.py:111)."""
+    import layers
+    for tag, (T_, Lw, V, dm, h, dk, att, seed) in {"msa_train_tiny": (6, 8, 40, 20, 2, 8, 12, 55),
+                                                   "msa_train_default": (72, 32, 500, 300, 16, 25, 256, 56)}.items():
+        state = synthetic.make_msa_state(V, dm, h, dk, att, seed=seed)
+        text, mask = synthetic.make_titles(T_, Lw, V, seed=seed + 1)
+        text[2], mask[2] = 0, False                                                            # an empty (all-padding) title
+        R = np.random.default_rng(seed + 2).standard_normal((T_, h * dk)).astype(np.float32)
+        mha = layers.MultiHeadAttention(h, dm, Lw, Lw, dk, dk)
+        attn = layers.Attention(h * dk, att)
+        mha.load_state_dict({k[len("multiheadSelfattention."):]: T(v) for k, v in state.items() if k.startswith("multiheadSelfattention.")})
+        attn.load_state_dict({k[len("attention."):]: T(v) for k, v in state.items() if k.startswith("attention.")})
+        emb = torch.nn.Embedding(V, dm)
+        emb.weight.data.copy_(T(state["word_embedding.weight"]))
+        mha.train(); attn.train()
+        w = emb(T(text))                                                                       # newsEncoders.py:76 (dropout 0)
+        hfeat = torch.relu(mha(w, w, w))                                                       # :78
+        out = attn(hfeat, mask=T(mask.astype(np.int64)))                                       # :80
+        loss = (out * T(R)).sum()
+        loss.backward()
+        named = [("word_embedding.weight", emb.weight)] + [("multiheadSelfattention." + k, v) for k, v in mha.named_parameters()] \
+            + [("attention." + k, v) for k, v in attn.named_parameters()]
+        grads = {}
+        for k, v in named:
+            if tag == "msa_train_tiny":
+                grads["g_" + k] = v.grad.numpy()
+            else:
+                grads.update(grad_digest(k, v.grad.numpy()))
+        save(f"{tag}.npz", meta=np.array([T_, Lw, V, dm, h, dk, att]), seeds=np.array([seed, seed + 1, seed + 2]),
+             input_checksum=checksum({"t": text, "m": mask, "r": R}, state), out_news_representation=out.detach().numpy(),
+             out_loss=loss.detach().numpy(), **grads)
+
+
 def fixture_sag():
     """SAG construction.  generate_news_graph (construct_SAG.py:449-485) is the reference function run
     unchanged on synthetic similarity dictionaries.  generate_cos_similarities (:112-162) moves its tensors with
@@ -531,6 +568,7 @@ def main():
             "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev),
             "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge),
             "ablation_train": lambda: fixture_ablation_train(ge), "msa": fixture_msa,
+            "msa_train": fixture_msa_train,
             "sag": fixture_sag, "devset_2k": lambda: fixture_devset_2k(ge, ev)}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]        # python oracle/make_golden.py [name ...]
     for name in (only or list(jobs)):

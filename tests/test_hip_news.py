@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import check_grad_digest, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,7 @@ def test_msa_hip_batch_on_the_matrix_core_path_matches_oracle():
         want = news_oracle.msa_forward({k: torch.from_numpy(v) for k, v in state.items()}, torch.from_numpy(text),
                                        torch.from_numpy(mask), h)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
-    # eval-mode forward with grad enabled falls back to the stock modules: same numbers within fp32 reassociation
+    # eval-mode forward with grad enabled runs the training pair without dropout: same numbers within fp32 reassociation
     stock = enc(torch.from_numpy(text[:8]).to(_dev()).unsqueeze(0), torch.from_numpy(mask[:8]).to(_dev()).unsqueeze(0))
     np.testing.assert_allclose(stock.detach().cpu().numpy()[0], want.numpy()[:8], rtol=1e-4, atol=1e-5)
 
@@ -70,3 +70,91 @@ def test_news_cache_in_batches_equals_one_call():
     with torch.no_grad():
         b = enc(tt, tm)
     assert torch.equal(a, b)
+
+
+# ---- training: digat_msa_fwd_train / digat_msa_bwd / digat_embedding_bwd ------------------------------------------------
+def _train_case(name, dropout=0.0):
+    from digat_amd import synthetic
+    fx = load_golden(name)
+    T_, Lw, V, dm, h, dk, att = (int(v) for v in fx["meta"])
+    s_w, s_t, s_r = (int(v) for v in fx["seeds"])
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=s_w)
+    text, mask = synthetic.make_titles(T_, Lw, V, seed=s_t)
+    text[2], mask[2] = 0, False
+    R = np.random.default_rng(s_r).standard_normal((T_, h * dk)).astype(np.float32)
+    tot = sum(float(np.asarray(v, dtype=np.float64).sum()) for v in [text, mask, R] + list(state.values()))
+    assert abs(tot - float(fx["input_checksum"])) <= 1e-6 * max(1.0, abs(tot)), "synthetic generator drifted from the fixture's"
+    enc = _encoder(V, dm, h, dk, att, Lw, state)
+    enc.dropout.p = dropout
+    return fx, enc.train(), torch.from_numpy(text).to(_dev()), torch.from_numpy(mask).to(_dev()), torch.from_numpy(R).to(_dev())
+
+
+def _close(got, want, what, rtol=2e-4, atol=2e-6):
+    got, want = got.detach().cpu().numpy(), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite"
+    scale = max(float(np.abs(want).max()), 1e-12)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.maximum(np.abs(want), 0.05 * scale)
+    assert not (err > tol).any(), f"{what}: max|diff| {err.max():.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("name", ["msa_train_tiny.npz", "msa_train_default.npz"])
+def test_msa_training_step_matches_reference_autograd(name):
+    """Output, loss and every gradient (word embedding included) of one training step, dropout 0, against the reference's
+    autograd.  Tolerance as tests/test_hip_training.py: long fp32 sums in another order -> 2e-4 relative + 2e-6 absolute."""
+    fx, enc, text, mask, R = _train_case(name)
+    out = enc(text.unsqueeze(0), mask.unsqueeze(0)).squeeze(0)
+    loss = (out * R).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    _close(out, fx["out_news_representation"], "news representation", rtol=1e-5, atol=2e-6)
+    _close(loss, fx["out_loss"], "loss", rtol=2e-5, atol=1e-5)
+    for k, p in enc.named_parameters():
+        assert p.grad is not None, k
+        if "g_" + k in fx:
+            _close(p.grad, fx["g_" + k], "grad " + k)
+        else:
+            check_grad_digest(fx, k, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
+
+
+def test_msa_training_with_dropout_is_reproducible_and_finite():
+    def once():
+        torch.manual_seed(11)
+        fx, enc, text, mask, R = _train_case("msa_train_default.npz", dropout=0.2)
+        out = enc(text.unsqueeze(0), mask.unsqueeze(0)).squeeze(0)
+        (out * R).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), [p.grad.clone() for p in enc.parameters()]
+    o1, g1 = once()
+    o2, g2 = once()
+    assert torch.isfinite(o1).all() and all(torch.isfinite(g).all() for g in g1)
+    assert torch.equal(o1, o2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    fx = load_golden("msa_train_default.npz")
+    assert float((o1.cpu() - torch.from_numpy(fx["out_news_representation"])).abs().max()) > 1e-3      # the dropout is live
+
+
+@pytest.mark.parametrize("M,V,dm", [(5000, 50, 300), (700, 3000, 64), (64, 10, 8), (3, 4, 4), (20000, 3, 32)])
+def test_embedding_backward_sums_rows_per_token(M, V, dm):
+    """digat_embedding_bwd against index_add_ in float64: few tokens with very long runs (several reduction levels), many
+    tokens with short runs, a single chunk."""
+    from digat_amd import _lib
+    g = torch.Generator().manual_seed(M + V)
+    tokens = torch.randint(0, V, (M,), generator=g)
+    if M > 100:
+        tokens[: M // 2] = 0                                       # the padding token: one very long run
+    rows = torch.randn(M, dm, generator=g)
+    want = torch.zeros(V, dm, dtype=torch.float64).index_add_(0, tokens, rows.double())
+    dev = _dev()
+    stok, order = torch.sort(tokens.to(dev), stable=True)
+    stok, order = stok.to(torch.int32), order.to(torch.int32)
+    rows_d = rows.to(dev)
+    table = torch.zeros(V, dm, device=dev)
+    L = _lib.lib()
+    nb = L.digat_embedding_bwd_workspace_bytes(M, dm)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _lib.check(L.digat_embedding_bwd(rows_d.data_ptr(), dm, order.data_ptr(), stok.data_ptr(), M, dm, table.data_ptr(), ws.data_ptr(), nb,
+                                     _lib.stream_ptr()), "digat_embedding_bwd")
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert float((table.cpu().double() - want).abs().max()) <= 2e-5 * scale

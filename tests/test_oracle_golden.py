@@ -307,3 +307,28 @@ def test_ablation_train_step_matches_reference_autograd(name, tag):
             close(v.grad.numpy(), fx["g_" + k], "grad " + k)
         else:
             check_grad_digest(fx, k, v.grad.numpy(), 2e-5, "grad ")
+
+
+@pytest.mark.parametrize("name", ["msa_train_tiny.npz", "msa_train_default.npz"])
+def test_msa_train_step_oracle_matches_reference_autograd(name):
+    """The news oracle's autograd (oracle/news_oracle.py) against the reference modules' (msa_train_*.npz)."""
+    from digat_amd import synthetic
+    from oracle import news_oracle
+    fx = load_golden(name)
+    T_, Lw, V, dm, h, dk, att = (int(v) for v in fx["meta"])
+    s_w, s_t, s_r = (int(v) for v in fx["seeds"])
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=s_w)
+    text, mask = synthetic.make_titles(T_, Lw, V, seed=s_t)
+    text[2], mask[2] = 0, False
+    R = np.random.default_rng(s_r).standard_normal((T_, h * dk)).astype(np.float32)
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in state.items()}
+    out = news_oracle.msa_forward(p, torch.from_numpy(text), torch.from_numpy(mask), h)
+    loss = (out * torch.from_numpy(R)).sum()
+    loss.backward()
+    close(out.detach().numpy(), fx["out_news_representation"], "news representation")
+    close(loss.detach().numpy(), fx["out_loss"], "loss")
+    for k, v in p.items():
+        if "g_" + k in fx:
+            close(v.grad.numpy(), fx["g_" + k], "grad " + k)
+        else:
+            check_grad_digest(fx, k, v.grad.numpy(), 2e-5, "grad ")

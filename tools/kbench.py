@@ -158,8 +158,8 @@ def bench_msa(T=8192, Lw=32, V=30000, dm=300, h=16, dk=25, att=256):
             return enc(tt, tm)
 
     def stock():
-        with torch.enable_grad():           # eval mode + grad enabled = the stock torch modules
-            return enc(tt.unsqueeze(0), tm.unsqueeze(0))
+        with torch.no_grad():
+            return enc.forward_stock(tt.unsqueeze(0), tm.unsqueeze(0))
     a = hip()
     b = stock().detach()[0]
     m1, _ = timeit(hip, iters=10)
@@ -167,6 +167,43 @@ def bench_msa(T=8192, Lw=32, V=30000, dm=300, h=16, dk=25, att=256):
     flops = T * Lw * (2.0 * dm * 3 * h * dk + 2.0 * h * dk * att) + T * h * 4.0 * Lw * Lw * dk
     print(f"MSA news encoder T={T} titles x {Lw} tokens: HIP {m1:.2f} ms ({T/m1/1e3:.2f} M titles/s, {flops/m1/1e9:.1f} TFLOP/s fp32-eq)"
           f"   stock torch {m2:.2f} ms   max|diff| {float((a - b).abs().max()):.2e}")
+
+
+def bench_msa_train(T=6400, Lw=32, V=30000, dm=300, h=16, dk=25, att=256):
+    """One training step of the MSA news encoder (forward + backward, dropout 0.2): digat_msa_fwd_train / digat_msa_bwd /
+    digat_embedding_bwd against the stock PyTorch modules.  T = 6400 titles is the reference's step (64 impressions x
+    (5 candidates x 10 SAG nodes + 50 history items))."""
+    import types
+    from digat_amd import newsEncoders, synthetic
+    dev = torch.device("cuda:0")
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=1)
+    text, mask = synthetic.make_titles(T, Lw, V, seed=2)
+    cfg = types.SimpleNamespace(vocabulary_size=V, word_embedding_dim=dm, max_title_length=Lw, dropout_rate=0.2,
+                                MSA_head_num=h, MSA_head_dim=dk, attention_dim=att)
+    enc = newsEncoders.MSA(cfg)
+    enc.load_state_dict({k_: torch.from_numpy(v) for k_, v in state.items()})
+    enc = enc.to(dev).train()
+    tt, tm = torch.from_numpy(text).to(dev).unsqueeze(0), torch.from_numpy(mask).to(dev).unsqueeze(0)
+    R = torch.randn(1, T, h * dk, device=dev)
+
+    def step(fn):
+        def run():
+            enc.zero_grad(set_to_none=True)
+            (fn(tt, tm) * R).sum().backward()
+        return run
+    m1, _ = timeit(step(enc), iters=10)
+    m2, _ = timeit(step(enc.forward_stock), iters=10)
+    M = T * Lw
+    flops = 3 * (M * (2.0 * dm * 3 * h * dk + 2.0 * h * dk * att)) + T * h * Lw * Lw * dk * 2.0 * 7
+    print(f"MSA training step T={T} titles x {Lw} tokens: HIP {m1:.2f} ms ({flops/m1/1e9:.1f} TFLOP/s fp32-eq)   stock torch {m2:.2f} ms")
+    from digat_amd import _lib
+    _lib.lib().digat_profile_start(4096)
+    step(enc)()
+    torch.cuda.synchronize()
+    import ctypes as C
+    ms = (C.c_double * 7)(); wk = (C.c_double * 7)(); cn = (C.c_int * 7)()
+    _lib.lib().digat_profile_stop(ms, wk, cn)
+    print("   library kernel ms by kind (proj, linear, xattn, pool, topic, glue, agg):", [round(v, 3) for v in ms], list(cn))
 
 
 def bench_sag(n=30000, m=30000, dim=768, top_M=5, news_num=65238, hop=2, cpu_rows=32):
@@ -210,6 +247,8 @@ if __name__ == "__main__":
         bench_xattn(*nums, density="mind")
     elif what == "msa":
         bench_msa(*nums)
+    elif what == "msa-train":
+        bench_msa_train(*nums)
     elif what == "sag":
         bench_sag(*nums)
     elif what == "topic":
