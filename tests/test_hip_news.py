@@ -158,3 +158,50 @@ def test_embedding_backward_sums_rows_per_token(M, V, dm):
     torch.cuda.synchronize()
     scale = float(want.abs().max())
     assert float((table.cpu().double() - want).abs().max()) <= 2e-5 * scale
+
+
+def test_model_training_step_with_native_msa_equals_stock_msa():
+    """Model.forward (model.py:54-77) with the MSA news encoder feeding the DIGAT graph encoder: one training step (dropout 0)
+    with the news encoder on its HIP pair against the same step with the news encoder on stock PyTorch modules — the autograd
+    chain text -> MsaFused -> graph-encoder Functions -> loss, every parameter gradient."""
+    from digat_amd import synthetic
+    from digat_amd.model import Model
+    B, K, N, H, C, Lw, V, dm, heads, dk, att, L = 4, 3, 4, 10, 5, 16, 200, 40, 4, 20, 24, 2
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=N, max_history_num=H, category_num=C,
+                                graph_depth=L, dropout_rate=0.0, vocabulary_size=V, word_embedding_dim=dm, max_title_length=Lw,
+                                MSA_head_num=heads, MSA_head_dim=dk, attention_dim=att)
+    torch.manual_seed(3)
+    model = Model(cfg)
+    model.initialize()
+    with torch.no_grad():
+        model.graph_encoder.topic_node_embedding.normal_(0, 0.02)
+        model.news_encoder.word_embedding.weight.mul_(0.1)         # GloVe-like magnitudes: logits of order one (with N(0,1) rows
+        # the loss is ~10 and a 3e-7 difference between the two news encoders flips ReLU gates of the graph encoder: its own
+        # gradients then differ by percents between the two runs — measured; an ill-conditioned test, not a defect)
+    model = model.to(_dev()).train()
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, heads * dk, seed=5)
+    users = synthetic.make_encoder_batch(B, N, H, C, heads * dk, seed=6, empty_history_rows=(1,))
+    nt, nm = synthetic.make_titles(B * K * N, Lw, V, seed=7)
+    ut, um = synthetic.make_titles(B * H, Lw, V, seed=8)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+    args = (d(ut).view(B, H, Lw), d(um).view(B, H, Lw), d(users["user_graph"]), d(users["user_category_mask"]),
+            d(users["user_category_indices"]), d(nt).view(B, K, N, Lw), d(nm).view(B, K, N, Lw),
+            d(flat["news_graph"]).view(B, K, N, N), d(flat["news_graph_mask"]).view(B, K, N))
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        logits = model(*args)
+        loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+    loss_hip, g_hip = step()
+    enc = model.news_encoder
+    enc.forward = enc.forward_stock
+    try:
+        loss_stock, g_stock = step()
+    finally:
+        del enc.forward
+    assert abs(float(loss_hip) - float(loss_stock)) <= 1e-5 * max(1.0, abs(float(loss_stock)))
+    for k in g_stock:
+        _close(g_hip[k], g_stock[k].cpu().numpy(), "grad " + k, rtol=2e-4, atol=1e-7)
