@@ -259,7 +259,7 @@ int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream
 
 // BASELINE configs[4], training half: the >= 2048-row GEMMs of the training path (projections, featureAffine, input
 // gradients) with ONE bf16 product per fp32 product — plain bf16 mixed precision: fp32 master weights and activations, bf16
-// matrix-core operands, fp32 accumulation — instead of the six of the fp32-grade split.  Weight gradients stay on the fp32 MFMA.
+// matrix-core operands, fp32 accumulation — instead of the six of the fp32-grade split (the >= 2048-row weight gradients included: gemm_tn_bf16x6_kernel<true>).
 static int g_train_bf16 = 0;
 int digat_set_train_precision(int bf16) {
     const int prev = g_train_bf16;

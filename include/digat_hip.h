@@ -318,9 +318,9 @@ int digat_xattn_pairwise_bwd(const float* dOut, const float* out, const float* X
 int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* stream);          /* dr[b] = sum_j dP[b,j] */
 
 /* BASELINE configs[4], training half.  1: the >= 2048-row GEMMs of the training path (Eq. 8 projections, featureAffine,
- * their input gradients) run with ONE bf16 product per fp32 product — bf16 mixed precision: fp32 master weights and
- * activations, bf16 matrix-core operands, fp32 accumulation; 0 (default): the fp32-grade six-product split.  Weight gradients,
- * the [B,d] linears and every reduction stay fp32.  Returns the previous setting. */
+ * their input and weight gradients) run with ONE bf16 product per fp32 product — bf16 mixed precision: fp32 master weights and
+ * activations, bf16 matrix-core operands, fp32 accumulation; 0 (default): the fp32-grade six-product split.  The [B,d] linears
+ * (and their weight gradients) and every reduction stay fp32.  Returns the previous setting. */
 int digat_set_train_precision(int bf16);
 
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
