@@ -85,6 +85,9 @@ def parse_args():
                     help="--mode train: bf16 = bf16 matrix-core operands for the large training GEMMs (BASELINE configs[4])")
     ap.add_argument("--per-row-users", action="store_true",
                     help="expand the user tensors per row as the reference's driver does (default: once per impression)")
+    ap.add_argument("--train-news-encoder", default="table", choices=["table", "msa"],
+                    help="--mode train: 'table' = news representations from a trainable table (graph-encoder step only); 'msa' = the "
+                         "reference's full step, MSA news encoder on the titles of 64 x (5 x N + H) news per step")
     ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
                          "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one)")
@@ -148,11 +151,24 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
     state = synthetic.make_state_dict(d, C, L, seed=0, bias_std=0.05)
     cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=N, max_history_num=H,
                                 category_num=C, graph_depth=L, dropout_rate=wl["dropout"])
-    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding), trainable=trainable))
+    text_encoder = trainable and getattr(args, "train_news_encoder", "table") == "msa"
+    if text_encoder:        # the reference's full training step: the MSA news encoder on title text (synthetic tokens, random init)
+        cfg.vocabulary_size, cfg.word_embedding_dim, cfg.max_title_length = 30000, 300, 32
+        cfg.MSA_head_num, cfg.MSA_head_dim, cfg.attention_dim = 16, 25, 256
+        model = Model(cfg)
+        model.news_encoder.initialize()
+        with torch.no_grad():
+            model.news_encoder.word_embedding.weight.mul_(0.1)          # GloVe-like magnitudes
+    else:
+        model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding), trainable=trainable))
     model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(D.dev)
     model.graph_encoder.projection_mode = args.projection
     dc = util.DeviceCorpus.from_numpy(corpus, D.dev)
+    if text_encoder:
+        text, mask = synthetic.make_titles(news_num, cfg.max_title_length, cfg.vocabulary_size, seed=7)
+        dc.title_text = torch.from_numpy(text).to(torch.int32).to(D.dev)
+        dc.title_mask = torch.from_numpy(mask).to(D.dev)
     W = types.SimpleNamespace(name=name, wl=wl, spec=spec, corpus=corpus, model=model, dc=dc, state=state, cfg=cfg,
                               N=N, H=H, C=C, d=d, L=L, mean_cand=corpus.rows / float(spec.impressions), setup_ms=None)
     if not trainable:
@@ -508,6 +524,8 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": W.wl["label"].replace("dev inference", "training").replace("fp32 ", ""), "behaviours_per_rank_step": 64,
                            "candidates_per_behaviour": 5, "rows_per_rank_step": 320, "dropout": W.wl["dropout"],
+                           "news_encoder": ("MSA on title text: %d titles x 32 tokens per rank and step" % (64 * (5 * W.N + W.H))
+                                            if args.train_news_encoder == "msa" else "trainable table of news representations"),
                            "parallelism": f"ddp{D.world} (DistributedDataParallel, RCCL all-reduce of the gradients)"},
                 "final_loss": run.loss}))
         D.close()

@@ -131,6 +131,18 @@ class Trainer:
         B, K = news.shape
         node_ids = dc.news_node_ID.index_select(0, news.flatten()).view(B, K, -1, 1)  # [B,K,N,1]
         hist = dc.history.index_select(0, imp).unsqueeze(2)                        # [B,H,1]
+        if dc.title_text is not None:          # a text news encoder (MSA): the titles of the history and of the SAG nodes, as
+            Lw = dc.title_text.shape[1]        # MIND_dataset.py hands them to model.forward (trainer.py:88-96)
+            def titles(ids):
+                flat = ids.reshape(-1)
+                return (dc.title_text.index_select(0, flat).view(*ids.shape[:-1], Lw),
+                        dc.title_mask.index_select(0, flat).view(*ids.shape[:-1], Lw))
+            ht, hm = titles(hist)
+            nt, nm = titles(node_ids)
+            return (ht, hm, dc.user_graph.index_select(0, imp), dc.user_category_mask.index_select(0, imp),
+                    dc.user_category_indices.index_select(0, imp), nt, nm,
+                    dc.news_graph.index_select(0, news.flatten()).view(B, K, *dc.news_graph.shape[1:]),
+                    dc.news_graph_mask.index_select(0, news.flatten()).view(B, K, -1))
         return (hist, torch.ones_like(hist, dtype=torch.bool), dc.user_graph.index_select(0, imp),
                 dc.user_category_mask.index_select(0, imp), dc.user_category_indices.index_select(0, imp),
                 node_ids, torch.ones_like(node_ids, dtype=torch.bool),

@@ -45,6 +45,8 @@ class DeviceCorpus:
     user_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, d]: layer 0's user-graph [h|P|Q] of every news as a history node
     topic_hpq0: Optional[torch.Tensor] = None                # [3, C, d]: ... of the topic nodes
     weights_key: Optional[tuple] = None                      # the weight version the five caches above were computed from
+    title_text: Optional[torch.Tensor] = None                # [news_num, Lw] int32 token ids (MIND_corpus.py: news_title_text)
+    title_mask: Optional[torch.Tensor] = None                # [news_num, Lw] bool                       (news_title_mask)
 
     @classmethod
     def from_numpy(cls, corpus, device) -> "DeviceCorpus":

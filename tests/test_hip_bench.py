@@ -70,3 +70,16 @@ def test_bench_train_mode_two_ranks_ddp():
     assert line["n_gpus"] == 2 and line["unit"] == "rows/s" and line["value"] > 0 and "ddp2" in line["config"]["parallelism"]
     import math
     assert math.isfinite(line["final_loss"])
+
+
+def test_bench_train_mode_with_the_msa_news_encoder():
+    """--mode train --train-news-encoder msa: the reference's full step (title text -> MSA -> graph encoder), native forward and
+    backward end to end."""
+    cmd = [sys.executable, "bench.py", "--mode", "train", "--train-news-encoder", "msa", "--steps", "3", "--warmup", "1",
+           "--impressions", "400", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    import math
+    assert line["unit"] == "rows/s" and line["value"] > 0 and math.isfinite(line["final_loss"])
+    assert "MSA" in line["config"]["news_encoder"]
