@@ -186,8 +186,8 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
 
 class Scorer:
     """The driver's scoring loop (util.score_rows) over the dev rows in order: the grouped inputs of batch k+1 are gathered
-    on a side stream while batch k is scored (util.GroupedBatchPipeline), consecutive batches alternate over two HIP
-    streams (util.batch_streams).  Batches are taken in order and wrap around only when the corpus is exhausted
+    on a side stream while batch k is scored (util.GroupedBatchPipeline), consecutive batches alternate over three HIP
+    streams (util.batch_streams; env DIGAT_BENCH_LANES).  Batches are taken in order and wrap around only when the corpus is exhausted
     (``revisited`` says whether that happened)."""
     CHUNK = 512                                    # batches per pipeline instance (index arrays are built per instance)
 
@@ -197,7 +197,7 @@ class Scorer:
         self.per_row = args.per_row_users
         self.nbatches = max(1, W.dc.rows // self.B)
         self.imp_host = W.corpus.row_impression
-        self.lanes = util.batch_streams(D.dev, int(os.environ.get("DIGAT_BENCH_LANES", "2")))
+        self.lanes = util.batch_streams(D.dev, int(os.environ.get("DIGAT_BENCH_LANES", "3")))
         self.nlanes = len(self.lanes)
         self.lane_scores = [torch.empty(self.B, dtype=torch.float32, device=D.dev) for _ in self.lanes]
         self.k, self.base, self.pipe, self.order = 0, 0, None, None
@@ -348,7 +348,7 @@ def rooflines(W, run, args):
     prof, prof_iso = run.prof, run.prof_iso
     kinds = {k: v for k, v in prof.items() if v["launches"] > 0}
     # dominant = the kind with the largest SOLO time per step (the untimed single-stream pass): inside the timed region the
-    # chip is shared by two batches and the side stream, and a launch's duration there says how long it waited, not what it cost
+    # chip is shared by three batches and their side streams, and a launch's duration there says how long it waited, not what it cost
     iso_ms = {k: prof_iso[k]["ms"] / max(1, run.iso_steps) for k in kinds if prof_iso.get(k, {}).get("launches", 0) > 0}
     dom = max(iso_ms, key=iso_ms.get) if iso_ms else max(kinds, key=lambda k: kinds[k]["ms"])
     symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(enc, "projection_mode", "") != "fp32"

@@ -301,11 +301,17 @@ class GroupedBatchPipeline:
 _batch_streams = {}
 
 
-def batch_streams(device, count: int = 2):
+def batch_streams(device, count: int = 3):
     """[current stream, extra streams ...] for scoring consecutive batches on alternating streams: a batch begins with
     small input-only kernels (user-node build, liveness, layer-0 projections of the groups) and ends with the last
-    user context on the library's side stream — on one stream the GPU idles through both; with two, batch k+1's opening
-    runs under batch k's last layer.  Every stream has its own scratch (``_lib.workspace`` is keyed by stream)."""
+    user context on the library's side stream — on one stream the GPU idles through both; with more, batch k+1's opening
+    runs under batch k's last layer.  Every stream has its own scratch (``_lib.workspace`` is keyed by stream).
+    Measured per 1024-row step (MIND-small shapes): 1 stream 1.48 ms, 2: 1.43, **3: 1.36**, 4: 1.48 — three batches in
+    flight fill the phases where a batch has a single latency-bound kernel running (a kernel trace of the 2-stream run:
+    no kernel 11 % of the time, one kernel 36 %).  The optimum depends on how the runtime maps the 2 x count + 1 streams to
+    its 4 hardware queues: with 5 or more queues (GPU_MAX_HW_QUEUES) every count is slower (2.0-2.2 ms) — more kernels truly
+    concurrent contend for the chip; without the library's side streams (DIGAT_SINGLE_STREAM=1) two streams do as well as
+    three with them (1.37 ms), one is worse (1.63 vs 1.48)."""
     cur = torch.cuda.current_stream(device)
     extra = _batch_streams.setdefault((device, cur.cuda_stream), [])
     while len(extra) < count - 1:
@@ -314,7 +320,7 @@ def batch_streams(device, count: int = 2):
 
 
 def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True,
-               streams: int = 2) -> torch.Tensor:
+               streams: int = 3) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
     tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``.  ``streams``:
     consecutive batches alternate over this many HIP streams (same kernels, same bits: see ``batch_streams``)."""
