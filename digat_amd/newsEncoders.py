@@ -101,8 +101,9 @@ class MsaFused(torch.autograd.Function):
         ws = _lib.workspace(nws, dev, "msa_train")
         p = float(p_drop)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-        _lib.check(L.digat_msa_fwd_train(P, tokens.data_ptr(), mask.data_ptr(), out.data_ptr(), p, seed, T, Lw, save.data_ptr(), nsave,
-                                         ws.data_ptr(), nws, _lib.stream_ptr()), "digat_msa_fwd_train")
+        if T:
+            _lib.check(L.digat_msa_fwd_train(P, tokens.data_ptr(), mask.data_ptr(), out.data_ptr(), p, seed, T, Lw, save.data_ptr(),
+                                             nsave, ws.data_ptr(), nws, _lib.stream_ptr()), "digat_msa_fwd_train")
         ctx.save_for_backward(tokens, mask, save, *ws_)
         ctx.dims, ctx.p, ctx.sizes = (heads, dk), p, (nsave, nws)
         return out
@@ -117,6 +118,9 @@ class MsaFused(torch.autograd.Function):
         T, Lw = tokens.shape
         dm, hd, att = table.shape[1], heads * dk, A1.shape[0]
         dev = tokens.device
+        if T == 0:                                # no title: every gradient is zero
+            z = [torch.zeros_like(w) for w in ws_]
+            return (None, None, z[0] if ctx.needs_input_grad[2] else None, *z[1:], None, None, None)
         dout = dout.float().contiguous()
         P = MsaFused._params(*ws_, heads, dk)
         nsave, nws = ctx.sizes

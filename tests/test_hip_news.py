@@ -205,3 +205,31 @@ def test_model_training_step_with_native_msa_equals_stock_msa():
     assert abs(float(loss_hip) - float(loss_stock)) <= 1e-5 * max(1.0, abs(float(loss_stock)))
     for k in g_stock:
         _close(g_hip[k], g_stock[k].cpu().numpy(), "grad " + k, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("T_,Lw,V,dm,h,dk,att", [(0, 16, 50, 32, 2, 8, 12), (1, 1, 30, 16, 1, 4, 4), (140, 20, 300, 64, 5, 16, 100),
+                                                  (70, 32, 200, 36, 3, 32, 20), (5, 7, 40, 12, 4, 3, 8)])
+def test_msa_training_shapes_against_the_oracle_autograd(T_, Lw, V, dm, h, dk, att):
+    """Other shapes than the fixtures': no title, a one-token title, 2 800 token rows with 16-wide heads (the matrix-core paths
+    with a padded attention_dim), the widest head (32), odd sizes on the fp32 paths — output and gradients vs the oracle."""
+    from digat_amd import synthetic
+    from oracle import news_oracle
+    state = synthetic.make_msa_state(V, dm, h, dk, att, seed=T_ + Lw)
+    text, mask = synthetic.make_titles(T_, Lw, V, seed=T_ + Lw + 1)
+    R = np.random.default_rng(T_).standard_normal((T_, h * dk)).astype(np.float32)
+    enc = _encoder(V, dm, h, dk, att, Lw, state).train()
+    enc.dropout.p = 0.0
+    out = enc(torch.from_numpy(text).to(_dev()).unsqueeze(0), torch.from_numpy(mask).to(_dev()).unsqueeze(0)).squeeze(0)
+    (out * torch.from_numpy(R).to(_dev())).sum().backward()
+    torch.cuda.synchronize()
+    if T_ == 0:                                   # nothing to encode: an empty output and zero gradients
+        assert out.shape == (0, h * dk)
+        assert all(v.grad is not None and float(v.grad.abs().max()) == 0.0 for v in enc.parameters())
+        return
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in state.items()}
+    want = news_oracle.msa_forward(p, torch.from_numpy(text), torch.from_numpy(mask), h)
+    (want * torch.from_numpy(R)).sum().backward()
+    _close(out, want.detach().numpy(), "news representation", rtol=1e-5, atol=2e-6)
+    for k, v in enc.named_parameters():
+        assert v.grad is not None, k
+        _close(v.grad, p[k].grad.numpy(), "grad " + k)

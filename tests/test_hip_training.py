@@ -201,3 +201,59 @@ def test_trainer_reduces_loss_on_a_tiny_synthetic_task():
     assert len(trainer.auc) == 6 and all(0.0 <= v <= 1.0 for v in trainer.auc)
     assert 1 <= trainer.best_dev_epoch <= 6 and trainer.best_state is not None
     assert trainer.auc[-1] > trainer.auc[0], trainer.auc             # training on these impressions must show on their dev AUC
+
+
+@pytest.mark.parametrize("n,d", [(128, 64), (113, 48), (67, 400), (1, 32)])
+def test_eq8_and_gat_layers_backward_at_the_largest_graphs(n, d):
+    """The two layer pairs (digat_xattn_fwd_train / _bwd, digat_gat_fwd_train / _bwd) alone against the oracle's autograd at the
+    largest graph the ABI admits (DIGAT_MAX_NODES = 128: the pairwise backward then runs 32-channel chunks, 113 is the first
+    size that needs them), at the user graph's size and at a single node."""
+    from digat_amd import training
+    from oracle import digat_oracle as O
+    g = torch.Generator().manual_seed(n * 1000 + d)
+    B = 3
+    X = torch.randn(B, n, d, generator=g)
+    A = (torch.rand(B, n, n, generator=g) < min(1.0, 6.0 / n))
+    A |= torch.eye(n, dtype=torch.bool).unsqueeze(0)
+    A[1, 0] = False                                                  # a centre without any entry: uniform attention (E5)
+    ctx = torch.randn(B, d, generator=g)
+    dOut = torch.randn(B, n, d, generator=g)
+    w = {k: (torch.randn(*shape, generator=g) * scale) for k, shape, scale in
+         [("W", (d, d), d ** -0.5), ("bW", (d,), 0.1), ("F1", (d, d), d ** -0.5), ("F2", (d, d), d ** -0.5), ("F3", (d, d), d ** -0.5),
+          ("b3", (d,), 0.1), ("a", (1, d), d ** -0.5), ("a1", (1, d), d ** -0.5), ("a2", (1, d), d ** -0.5)]}
+    p = {"user_graph_attention_W.0.weight": w["W"], "user_graph_attention_W.0.bias": w["bW"],
+         "user_graph_attention_ffn1.0.weight": w["F1"], "user_graph_attention_ffn2.0.weight": w["F2"],
+         "user_graph_attention_ffn3.0.weight": w["F3"], "user_graph_attention_ffn3.0.bias": w["b3"],
+         "user_graph_attention_a.0.weight": w["a"], "user_graph_attention_a1.0.weight": w["a1"],
+         "user_graph_attention_a2.0.weight": w["a2"]}
+    p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Xo, co = X.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    (O.cross_graph_attention(p, "user", 0, Xo, A, co) * dOut).sum().backward()
+    want_x = {"X": Xo.grad, "ctx": co.grad, **{k: p["user_graph_attention_" + n_].grad for k, n_ in
+              [("W", "W.0.weight"), ("bW", "W.0.bias"), ("F1", "ffn1.0.weight"), ("F2", "ffn2.0.weight"), ("F3", "ffn3.0.weight"),
+               ("b3", "ffn3.0.bias"), ("a", "a.0.weight")]}}
+    for v in p.values():
+        v.grad = None
+    Xg = X.clone().requires_grad_(True)
+    (O.gat_layer(p, "user", 0, Xg, A) * dOut).sum().backward()
+    want_g = {"X": Xg.grad, "W": p["user_graph_attention_W.0.weight"].grad, "bW": p["user_graph_attention_W.0.bias"].grad,
+              "a1": p["user_graph_attention_a1.0.weight"].grad, "a2": p["user_graph_attention_a2.0.weight"].grad}
+
+    dv = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
+    Ab = A.to(torch.uint8).to(DEV).contiguous()
+    Xd, cd = X.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
+    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], 0.0)
+    (out * dOut.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    got = {"X": Xd.grad, "ctx": cd.grad, **{k: dv[k].grad for k in ("W", "bW", "F1", "F2", "F3", "b3", "a")}}
+    for k in want_x:
+        close(got[k], want_x[k].numpy(), f"Eq. 8 n={n} grad {k}")
+    for v in dv.values():
+        v.grad = None
+    Xd2 = X.to(DEV).requires_grad_(True)
+    out = training.GatFused.apply(Xd2, Ab, dv["W"], dv["bW"], dv["a1"], dv["a2"], 0.0)
+    (out * dOut.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    got = {"X": Xd2.grad, "W": dv["W"].grad, "bW": dv["bW"].grad, "a1": dv["a1"].grad, "a2": dv["a2"].grad}
+    for k in want_g:
+        close(got[k], want_g[k].numpy(), f"GAT n={n} grad {k}")
