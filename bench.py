@@ -409,8 +409,10 @@ def rooflines(W, run, args):
             o2 = roof_of(kind, iso)
             out["isolated_achieved"], out["isolated_frac"] = o2["achieved"], o2["frac"]
             out["isolated_avg_launch_ms"] = o2["avg_launch_ms"]
-            out["note"] = ("achieved/frac: launch durations inside the timed region, where news-graph kernels share the chip "
-                           "on a side stream; isolated_*: the same launches on a single stream (untimed pass)")
+            out["note"] = ("achieved/frac: launch durations inside the timed region, where three batches are in flight and each has "
+                           "its news-graph / user-context kernels on a side stream: a launch's duration there includes the time it "
+                           "shares the chip (more batches in flight = higher throughput and LONGER individual launches); "
+                           "isolated_*: the same launches on a single stream (untimed pass)")
         return out
 
     rx = None
