@@ -259,6 +259,25 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         for _ in range(8):
             sc.step()
         torch.cuda.synchronize()
+    # Setup, untimed: how many batches to keep in flight (util.batch_streams: 3 is best at the default shapes, 2 at the stress
+    # shape and with bf16 P', Q — the optimum moves with the kernels' lengths, so it is measured, 20 steps per candidate)
+    if "DIGAT_BENCH_LANES" not in os.environ and len(sc.lanes) >= 3:
+        best = None
+        for n in (2, 3):
+            sc.join()
+            sc.nlanes = n
+            for _ in range(4):
+                sc.step()
+            torch.cuda.synchronize()
+            t_n = time.perf_counter()
+            for _ in range(16):
+                sc.step()
+            torch.cuda.synchronize()
+            t_n = time.perf_counter() - t_n
+            if best is None or t_n < best[0]:
+                best = (t_n, n)
+        sc.join()
+        sc.nlanes = best[1]
     for _ in range(warmup):
         sc.step()
     if gather_scores:                      # N > 1: the timed steps keep their scores for the closing all_gather
@@ -284,6 +303,7 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
     D.fence()
     elapsed = time.perf_counter() - t0
     out = types.SimpleNamespace(elapsed=elapsed, rows_done=rows_done, profiled_steps=profiled_steps, revisited=sc.revisited,
+                                batches_in_flight=sc.nlanes,
                                 prof=None, prof_iso=None, live_fraction=None, iso_steps=0,
                                 gathered_rows=None if gathered is None else int(gathered.numel()))
     if with_profile:
@@ -568,7 +588,7 @@ def main():
             mc = evaluate.scoring(lab, evaluate.impression_ranks(cpu_scores, ri), ri)
             extra["mind-small-default/pq-bf16"] = {
                 "value": (r4.rows_done / W.mean_cand) / r4.elapsed, "unit": "impressions/s", "rows_per_s": r4.rows_done / r4.elapsed,
-                "ms_per_step": r4.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps,
+                "ms_per_step": r4.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps, "batches_in_flight": r4.batches_in_flight,
                 "dtype": "f32 with P', Q of Eq. 8 (user graph, layers >= 1) in bf16",
                 "max_abs_metric_diff_vs_fp32_oracle": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
                 "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
@@ -579,7 +599,8 @@ def main():
             r2 = run_inference(W2, args, D, args.extra_steps, 3, with_profile=False)
             extra[other] = {"value": (r2.rows_done / W2.mean_cand) / r2.elapsed, "unit": "impressions/s",
                             "rows_per_s": r2.rows_done / r2.elapsed, "ms_per_step": r2.elapsed / args.extra_steps * 1e3,
-                            "steps": args.extra_steps, "setup_ms": round(W2.setup_ms, 1), "config": workload_config(W2, args, D)}
+                            "steps": args.extra_steps, "batches_in_flight": r2.batches_in_flight, "setup_ms": round(W2.setup_ms, 1),
+                            "config": workload_config(W2, args, D)}
             del W2, r2
             torch.cuda.empty_cache()
 
@@ -602,6 +623,9 @@ def main():
         "config": workload_config(W, args, D),
         "rows_per_s": rows_total / elapsed,
         "batch_revisited_in_timed_region": bool(run.revisited),
+        # consecutive batches alternate over this many HIP streams (util.batch_streams); chosen between 2 and 3 by a short
+        # measurement before the warm-up unless DIGAT_BENCH_LANES says
+        "batches_in_flight": run.batches_in_flight,
         # prepare_news_side (SA gather, c_n0, the layer-0 tables): once per dev run and weight version, outside the timed region
         "setup_ms": round(W.setup_ms, 1),
         "setup_ms_per_step_amortised": {"over_this_corpus": round(W.setup_ms / nb_corpus, 4),
