@@ -1,8 +1,10 @@
-for cfg in "0 3" "64 3" "128 3" "32 3" "96 3" "64 2" "128 2" "192 3"; do
-  set -- $cfg
-  echo "== side CUs $1 lanes $2"
-  DIGAT_SIDE_CUS=$1 DIGAT_BENCH_LANES=$2 python bench.py --steps 150 --warmup 10 --extra-steps 0 --cpu-rows 0 2>/dev/null | tail -n 1 | python -c "
+for rep in 1 2; do
+for v in "" n3w7 n4w7 n3w6; do
+  lib=""; [ -n "$v" ] && lib="$PWD/tools/exp/libdigat_$v.so"
+  echo "== ${v:-default (n4w6)}"
+  DIGAT_HIP_LIB=$lib DIGAT_BENCH_LANES=3 python bench.py --steps 150 --warmup 10 --extra-steps 0 --cpu-rows 0 2>/dev/null | tail -n 1 | python -c "
 import sys, json
 j = json.loads(sys.stdin.readlines()[-1])
-print(j['value'], j['ms_per_step'], j['kernel_ms_per_step'])"
+print(j['value'], j['ms_per_step'], j['kernel_ms_per_step']['xattn'], j['kernel_ms_per_step_single_stream']['xattn'], j['roofline_xattn']['isolated_avg_launch_ms'])"
+done
 done
