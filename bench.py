@@ -558,6 +558,11 @@ def main():
     elapsed = D.reduce([run.elapsed], "max")[0]
     rows_total, rows_all, imps_all = D.reduce([run.rows_done, W.corpus.rows, W.spec.impressions])
     mean_cand = rows_all / imps_all                       # candidates per impression over every rank's shard
+    # every rank's own rate over its own clock (rows / its elapsed time): with no collective in the data path the job's rate
+    # is their sum up to the slowest rank's tail; compare with the single-GPU rate of the SAME workload (the N = 1 line's
+    # extra_workloads["mind-large-default"]) — the N = 1 headline is the MIND-small workload, BASELINE configs[1]
+    per_rank = D.reduce([(run.rows_done / run.elapsed) if r == D.rank else 0.0 for r in range(D.world)])
+    lanes_by_rank = D.reduce([float(run.batches_in_flight) if r == D.rank else 0.0 for r in range(D.world)])
     if D.rank != 0:
         D.close()
         return
@@ -625,7 +630,8 @@ def main():
         "batch_revisited_in_timed_region": bool(run.revisited),
         # consecutive batches alternate over this many HIP streams (util.batch_streams); chosen between 2 and 3 by a short
         # measurement before the warm-up unless DIGAT_BENCH_LANES says
-        "batches_in_flight": run.batches_in_flight,
+        "batches_in_flight": run.batches_in_flight if D.world == 1 else [int(v) for v in lanes_by_rank],
+        "per_rank_impressions_per_s": None if D.world == 1 else [round(v / mean_cand, 1) for v in per_rank],
         # prepare_news_side (SA gather, c_n0, the layer-0 tables): once per dev run and weight version, outside the timed region
         "setup_ms": round(W.setup_ms, 1),
         "setup_ms_per_step_amortised": {"over_this_corpus": round(W.setup_ms / nb_corpus, 4),

@@ -56,6 +56,7 @@ def test_bench_two_ranks_sum_their_rows():
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None       # rank 0 at N=1 only
     assert line["config"]["N"] == 26 and "MIND-large" in line["config"]["workload"]     # BASELINE configs[3]'s shape at N > 1
     assert line["auc_match"]["max_abs_metric_diff"] <= 1e-4
+    assert len(line["per_rank_impressions_per_s"]) == 2 and all(v > 0 for v in line["per_rank_impressions_per_s"])
 
 
 def test_bench_train_mode_two_ranks_ddp():
