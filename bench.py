@@ -88,7 +88,7 @@ def parse_args():
     ap.add_argument("--train-news-encoder", default="table", choices=["table", "msa"],
                     help="--mode train: 'table' = news representations from a trainable table (graph-encoder step only); 'msa' = the "
                          "reference's full step, MSA news encoder on the titles of 64 x (5 x N + H) news per step")
-    ap.add_argument("--projection", default="bf16x6", choices=["bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1"],
+    ap.add_argument("--projection", default="auto", choices=["auto", "bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1", "fp16x3"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
                          "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one)")
     return ap.parse_args()
@@ -371,7 +371,7 @@ def rooflines(W, run, args):
     # chip is shared by three batches and their side streams, and a launch's duration there says how long it waited, not what it cost
     iso_ms = {k: prof_iso[k]["ms"] / max(1, run.iso_steps) for k in kinds if prof_iso.get(k, {}).get("launches", 0) > 0}
     dom = max(iso_ms, key=iso_ms.get) if iso_ms else max(kinds, key=lambda k: kinds[k]["ms"])
-    symbols = {"proj": "gemm_bf16x6s_kernel<3>" if getattr(enc, "projection_mode", "") != "fp32"
+    symbols = {"proj": "gemm_bf16x6s_kernel<3" if getattr(enc, "projection_mode", "") != "fp32"
                else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>",
                "xattn": "xattn_sparse" if enc.resolved_xattn_mode("user") == "sparse" else "xattn_score_kernel",
                "agg": "xattn_agg_kernel", "topic": "topic_pool", "pool": "attn_pool_kernel"}
@@ -395,21 +395,24 @@ def rooflines(W, run, args):
     def roof_of(kind, v):
         per_launch_ms = v["ms"] / v["launches"]
         rate = v["work"] / (v["ms"] * 1e-3)
-        pmode = getattr(enc, "projection_mode", "fp32")
+        pmode = enc.resolved_projection_mode() if hasattr(enc, "resolved_projection_mode") else getattr(enc, "projection_mode", "fp32")
         if kind == "proj" and pmode != "fp32":
             # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split; "bf16x6-pq3": 6 for h,
             # 3 for P and Q = 4 on average): price the EXECUTED bf16 flops against the dense bf16 peak, and quote the
             # fp32-equivalent rate
-            nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-bf16-x1": 8.0 / 3.0}[pmode]
+            nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-bf16-x1": 8.0 / 3.0, "fp16x3": 3.0}[pmode]
             return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": nprod * rate / 1e12,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": nprod * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": pmc_traffic(kind),
-                    "mfma_dtype": "bf16 (3-way split of f32, f32 accumulate; products per fp32 product: %s)"
+                    "mfma_dtype": ("fp16 (2-way split of f32, f32 accumulate; products per fp32 product: %s)" if pmode == "fp16x3" else
+                                   "bf16 (3-way split of f32, f32 accumulate; products per fp32 product: %s)")
                                   % {"bf16x6": "6", "bf16x6-pq3": "6 for h, 3 for P and Q", "pq-bf16": "6 for h, 3 for P and Q",
-                                     "pq-bf16-x1": "6 for h, 1 for P and Q (user graph, layers >= 1)"}[pmode],
-                    "fp32_equivalent_tflops": rate / 1e12, "algorithmic_flops_per_launch": v["work"] / v["launches"],
+                                     "pq-bf16-x1": "6 for h, 1 for P and Q (user graph, layers >= 1)",
+                                     "fp16x3": "3 (two fp16 pieces per operand)"}[pmode],
+                    "fp32_equivalent_tflops": rate / 1e12, "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS,
+                    "algorithmic_flops_per_launch": v["work"] / v["launches"],
                     "executed_flops_per_launch": nprod * v["work"] / v["launches"],
-                    "peak_note": "nominal dense bf16 peak (2.4 GHz); on random operands the chip holds about 1.9-2.0 GHz "
+                    "peak_note": "nominal dense bf16 / fp16 peak (2.4 GHz); on random operands the chip holds about 1.9-2.0 GHz "
                                  "(MI355X_MICROARCH.md), i.e. about 2.0 PFLOP/s",
                     "avg_launch_ms": per_launch_ms, "launches": v["launches"]}
         if kind in ("proj", "linear"):
@@ -513,9 +516,17 @@ def cpu_baseline_and_auc(W, args, cpu_rows, cpu_seconds, report_baseline):
     return baseline, auc_match, (cpu_scores, n_rows)
 
 
+PROJECTION_DTYPE = {
+    "bf16x6": "f32 (matrix-core products of operands split into three bf16 pieces, six products, f32 accumulation)",
+    "fp16x3": "f32 (matrix-core products of operands split into two fp16 pieces, three products, f32 accumulation; error against "
+              "fp64 at or below an fp32 fma chain's: tests/test_hip_lowprec.py)",
+}
+
+
 def workload_config(W, args, D):
     enc = W.model.graph_encoder
-    return {"workload": W.wl["label"], "projection": args.projection,
+    return {"workload": W.wl["label"], "projection": args.projection + ("" if args.projection != "auto" else " -> " + enc.resolved_projection_mode()),
+            "projection_format": PROJECTION_DTYPE.get(enc.resolved_projection_mode(), enc.resolved_projection_mode()),
             "user_side": "per row" if args.per_row_users else "once per impression (row_group index)",
             "user_graph_eq8": enc.resolved_xattn_mode("user") + " (chosen from the corpus: mean adjacency entries per node)",
             "news_graph_eq8": ("small-graph kernel (n <= 16)" if W.N <= 16 else enc.resolved_xattn_mode("news")),
@@ -580,7 +591,7 @@ def main():
     if D.world == 1 and args.extra_steps > 0 and args.workload == "auto":
         # BASELINE configs[2] and the configs[3] shape, a few steps each, in the same invocation (same method, fewer steps)
         extra = {}
-        if args.projection == "bf16x6" and cpu_sample is not None:
+        if args.projection in ("auto", "bf16x6") and cpu_sample is not None:
             # BASELINE configs[4], inference half: the same workload with P', Q of Eq. 8 stored in bf16 (projection_mode
             # "pq-bf16"); metric drift on the rows of the CPU sample against the fp32 oracle
             from digat_amd import evaluate, util
@@ -598,7 +609,24 @@ def main():
                 "max_abs_metric_diff_vs_fp32_oracle": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
                 "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
                 "rows_compared": int(n_rows)}
+            # the same workload under the OTHER operand format of the matrix-core GEMMs: "bf16x6" (three bf16 pieces, six products, no
+            # range limit) when the headline ran "fp16x3" (two fp16 pieces, three products; what "auto" picks for weights below 32)
             W.model.graph_encoder.projection_mode = args.projection
+            other_pm = "bf16x6" if W.model.graph_encoder.resolved_projection_mode() == "fp16x3" else "fp16x3"
+            W.model.graph_encoder.projection_mode = other_pm
+            util.prepare_news_side(W.model.graph_encoder, W.dc, args.batch)
+            r5 = run_inference(W, args, D, args.extra_steps, 3, with_profile=False)
+            sc = util.score_rows(W.model, W.dc, 0, n_rows, args.batch).cpu().numpy()
+            mg = evaluate.scoring(lab, evaluate.impression_ranks(sc, ri), ri)
+            extra["mind-small-default/" + other_pm] = {
+                "value": (r5.rows_done / W.mean_cand) / r5.elapsed, "unit": "impressions/s", "rows_per_s": r5.rows_done / r5.elapsed,
+                "ms_per_step": r5.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps, "batches_in_flight": r5.batches_in_flight,
+                "dtype": PROJECTION_DTYPE[other_pm],
+                "max_abs_metric_diff_vs_fp32_oracle": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
+                "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
+                "rows_compared": int(n_rows)}
+            W.model.graph_encoder.projection_mode = args.projection
+            util.prepare_news_side(W.model.graph_encoder, W.dc, args.batch)
         for other in ("mind-small-stress", "mind-large-default"):
             W2 = build_workload(other, args, D, 4096)
             r2 = run_inference(W2, args, D, args.extra_steps, 3, with_profile=False)
@@ -622,6 +650,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        # fp32 data and fp32-grade arithmetic; how the >= 2048-row GEMMs form their fp32 products on the matrix cores is
+        # config.projection / config.projection_format
         "dtype": "f32" if not args.projection.startswith("pq-bf16") else "f32 with P', Q of the user graph's Eq. 8 in bf16 (configs[4])",
         "data": "synthetic",
         "valid": bool(matched or auc_match is None),

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "digat_set_live_row_skipping": (C.c_int, [C.c_int]),
     "digat_set_staged_xattn": (C.c_int, [C.c_int]),
     "digat_set_train_precision": (C.c_int, [C.c_int]),
+    "digat_set_gemm_format": (C.c_int, [C.c_int]),
+    "digat_get_gemm_format": (C.c_int, []),
     "digat_profile_live_row_fraction": (C.c_double, []),
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
     "digat_gat_workspace_bytes": (C.c_size_t, [C.c_int] * 3),

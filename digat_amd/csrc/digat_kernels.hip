@@ -242,10 +242,18 @@ static int launch_split(const float* w0, const float* w1, const float* w2, int n
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit, transposed);
+    hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit, transposed,
+                       gemm_format_f16() ? 2 : 3);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
+
+int digat_set_gemm_format(int format) {
+    const int prev = g_gemm_format;
+    g_gemm_format = format ? 1 : 0;
+    return prev;
+}
+int digat_get_gemm_format(void) { return g_gemm_format; }
 
 int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream) {
     if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;

@@ -75,8 +75,12 @@ class DIGAT(GraphEncoder):
         # node projections: "bf16x6" = fp32-equivalent product on the bf16 matrix cores (default), "bf16x6-pq3" = the same
         # for h, three of the six products for P and Q (they only feed the score: DIGAT_PROJ_PQ_X3), "fp32" = v_mfma_f32_16x16x4_f32;
         # BASELINE configs[4]: "pq-bf16" = pq3 + P', Q of the user graph's layers >= 1 STORED in bf16 (DIGAT_PQ_BF16; the
-        # reference's quantised K3 + K1 + K2, README.md:62-66), "pq-bf16-x1" = the same with one bf16 product for P and Q
-        self.projection_mode = "bf16x6"
+        # reference's quantised K3 + K1 + K2, README.md:62-66), "pq-bf16-x1" = the same with one bf16 product for P and Q;
+        # "fp16x3" = every operand as two fp16 pieces, three products (digat_set_gemm_format(1): 0.7x the GEMM time, error at or
+        # below an fp32 fma chain's against fp64 for |w| < 63, |x| < 4094 — fp16's range after the format's scaling);
+        # "auto" (default) = "fp16x3" when every projected weight is below 32 in magnitude, else "bf16x6" (no range limit)
+        self.projection_mode = "auto"
+        self._resolved_pm = None
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
         self.user_xattn_mode = "auto"
@@ -120,6 +124,10 @@ class DIGAT(GraphEncoder):
         return super()._apply(fn, *args, **kwargs)
 
     def _params(self) -> "_lib.Params":
+        # the matrix-core operand format is a process-wide library setting: every call of this encoder sets its own
+        # ("fp16x3": two fp16 pieces, three products; everything else: three bf16 pieces, six products)
+        pm = self.resolved_projection_mode()
+        _lib.lib().digat_set_gemm_format(1 if pm == "fp16x3" else 0)
         ptrs = tuple(p.data_ptr() for p in self.parameters())
         if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
             # the Eq. 8 variant only selects kernels (P.flags): it never invalidates the split weights or the folded
@@ -159,7 +167,7 @@ class DIGAT(GraphEncoder):
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
         # bf16x6 projections: split [W | ffn1 | ffn2] of every layer into three bf16 planes (once per weight version)
         P._splits = []
-        if self.projection_mode in ("bf16x6", "bf16x6-pq3", "pq-bf16", "pq-bf16-x1") and self.news_embedding_dim % 80 == 0:
+        if pm in ("bf16x6", "bf16x6-pq3", "pq-bf16", "pq-bf16-x1", "fp16x3") and self.news_embedding_dim % 80 == 0:
             L_ = _lib.lib()
             d = self.news_embedding_dim
             nbytes = L_.digat_split_weights_bytes(3 * d, d)
@@ -187,6 +195,20 @@ class DIGAT(GraphEncoder):
         self._param_block = (ptrs, P, self._fold_key())
         return P
 
+    def resolved_projection_mode(self) -> str:
+        """``projection_mode`` with "auto" resolved from the weights' range (once per weight version; one host sync)."""
+        if self.projection_mode != "auto":
+            return self.projection_mode
+        if self.news_embedding_dim % 80 != 0:
+            return "bf16x6"
+        ws = [m.weight for g in ("news", "user") for f in ("W", "ffn1", "ffn2") for m in getattr(self, f"{g}_graph_attention_{f}")]
+        ws.append(self.featureAffine.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._resolved_pm is None or self._resolved_pm[0] != key:
+            wmax = float(torch.stack([w.detach().abs().max() for w in ws]).max())
+            self._resolved_pm = (key, "fp16x3" if wmax < 32.0 else "bf16x6")       # nan compares false: bf16x6
+        return self._resolved_pm[1]
+
     def _flags(self) -> int:
         """digat_params.flags (include/digat_hip.h): Eq. 8 variant of the user graph (bits 0-1), DIGAT_PROJ_PQ_X3 (bit 2),
         DIGAT_NEWS_XATTN_SPARSE (bit 3)."""
@@ -203,7 +225,7 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.projection_mode) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.resolved_projection_mode()) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))

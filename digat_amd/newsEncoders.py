@@ -212,7 +212,8 @@ class MSA(NewsEncoder):
               self.multiheadSelfattention.W_K.weight, self.multiheadSelfattention.W_V.weight,
               self.multiheadSelfattention.W_V.bias, self.attention.affine1.weight, self.attention.affine1.bias,
               self.attention.affine2.weight]
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        from . import _lib as _l
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (_l.lib().digat_get_gemm_format(),)   # split images are per format
         cached = getattr(self, "_hip_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]

@@ -148,7 +148,8 @@ def weights_key(encoder, dc: DeviceCorpus) -> tuple:
     """What the per-news caches of ``prepare_news_side`` depend on: every encoder parameter's storage and version counter
     (an optimizer step or ``load_state_dict`` bumps them) and the news representations they were computed from."""
     params = tuple((p.data_ptr(), p._version) for p in encoder.parameters()) if hasattr(encoder, "parameters") else ()
-    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, getattr(encoder, "projection_mode", None))
+    pm = encoder.resolved_projection_mode() if hasattr(encoder, "resolved_projection_mode") else getattr(encoder, "projection_mode", None)
+    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm)
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):

@@ -323,6 +323,19 @@ int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* strea
  * (and their weight gradients) and every reduction stay fp32.  Returns the previous setting. */
 int digat_set_train_precision(int bf16);
 
+/* The operand format of the >= 2048-row matrix-core GEMMs (node projections, featureAffine, the MSA encoder's, the training
+ * path's): 0 (default) = every fp32 value as three bf16 pieces, six products — as accurate as an fp32 fma chain; 1 ("fp16x3") =
+ * two fp16 pieces (22-23 significant bits), three products on v_mfma_f32_16x16x32_f16: 0.7x the time.  The weights are scaled by
+ * 2^10 and the activations by 2^4 on their way in (exact; undone in the epilogue) so that the low pieces of ordinary values are
+ * normal fp16 numbers: against fp64 its mean and largest errors are at or below an fp32 fma chain's (tests/test_hip_lowprec.py)
+ * for |w| < 63 and 0.01 < |x| < 4094; beyond the upper bounds the result is inf, far below the lower one the pieces are
+ * subnormal (an absolute floor of 2^-24 per term).  Process-wide; a split image (digat_split_*) must be used under the setting it was made under.
+ * Returns the previous setting.  Initial value: env DIGAT_GEMM_F16X3.  The training entries (digat_*_fwd_train, digat_*_bwd,
+ * digat_linear_bwd_input_x3, digat_xattn_project_x3) always use format 0: gradients have no lower bound (1e-6 and below is
+ * ordinary) and fp16 pieces of such values are subnormal or zero; bf16 pieces keep fp32's exponent range. */
+int digat_set_gemm_format(int format);
+int digat_get_gemm_format(void);
+
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
  * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one
  * autograd.Function.  `save` is a caller-owned buffer carrying what the backward needs from the forward (private layout,

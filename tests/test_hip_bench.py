@@ -39,7 +39,10 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert rx["bound"] == "hbm" and 0 < rx["frac"] < 1
     assert line["setup_ms"] > 0 and line["config"]["news_num"] == 2048
     ex = line["extra_workloads"]
-    assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16"} and all(v["value"] > 0 for v in ex.values())
+    assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16", "mind-small-default/bf16x6"}
+    assert all(v["value"] > 0 for v in ex.values())
+    assert "fp16x3" in line["config"]["projection"] and "two fp16 pieces" in line["config"]["projection_format"]
+    assert ex["mind-small-default/bf16x6"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4
     assert ex["mind-small-default/pq-bf16"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4          # BASELINE configs[4], inference half
     assert ex["mind-small-stress"]["config"]["N"] == 65 and ex["mind-large-default"]["config"]["N"] == 26
 

@@ -102,3 +102,54 @@ def test_bf16_eq8_operands_on_the_small_devsets(name):
     np.testing.assert_allclose(metrics, fx["metrics"], rtol=0, atol=1e-4)
     ref = fx["scores"]
     print(f"\n[{name} pq-bf16] max rel score diff {np.max(np.abs(scores - ref) / (np.abs(ref) + 1e-3)):.3e}")
+
+
+def test_fp16x3_projections_keep_scores_and_metrics():
+    """projection_mode "fp16x3" (digat_set_gemm_format(1)): every matrix-core operand as two fp16 pieces, three products.  On the
+    reference-pinned 2 000-impression dev set the scores stay within 1e-4 relative of the reference's and the metrics within
+    1e-5 — a tenth of the reference's criterion — while the projections take 0.7x the time."""
+    from digat_amd import _lib, util
+    fx, corpus, model, dc = build_2k()
+    model.graph_encoder.projection_mode = "bf16x6"
+    base, base_metrics = util.compute_scores(model, dc, 1024, labels=corpus.row_label)
+    assert _lib.lib().digat_get_gemm_format() == 0
+    model.graph_encoder.projection_mode = "fp16x3"
+    scores, metrics = util.compute_scores(model, dc, 1024, labels=corpus.row_label)
+    assert _lib.lib().digat_get_gemm_format() == 1
+    assert not np.array_equal(scores, base), "the fp16x3 path did not run"
+    rel = report(scores, fx, "fp16x3")
+    drift = np.abs(np.array(metrics) - fx["metrics"])
+    print(f"[fp16x3] metric drift vs the reference {np.round(drift, 8)}; scores vs this library's bf16x6 path: max rel "
+          f"{np.max(np.abs(scores - base) / (np.abs(base) + 1e-3)):.3e}")
+    assert rel.max() < 1e-4 and drift.max() <= 1e-5, (rel.max(), drift)
+
+
+@pytest.mark.parametrize("M,N,K,scale", [(4100, 400, 400, 1.0), (34304, 1200, 400, 1.0), (4100, 400, 400, 100.0), (2500, 160, 72, 0.01)])
+def test_fp16x3_linear_error_against_fp64(M, N, K, scale):
+    """The two-piece fp16 product against an fp64 product, next to the fp32-MFMA kernel (an exact k-ordered fp32 fma chain) on the
+    same data: mean and max error at most 1.1x the chain's (measured 0.75x / 0.7x at unit scale, 1.0x for |x| ~ 0.01)."""
+    from digat_amd import _lib
+    rng = np.random.default_rng(M + N + K)
+    x = (rng.standard_normal((M, K)) * scale).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    xd, wd, bd = (torch.from_numpy(a).to(DEV) for a in (x, w, b))
+    L = _lib.lib()
+    y16 = torch.full((M, N), float("nan"), device=DEV)
+    y32 = torch.full((M, N), float("nan"), device=DEV)
+    ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=DEV)
+    prev = L.digat_set_gemm_format(1)
+    try:
+        _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y16.data_ptr(), N, M, N, K, ws.data_ptr(),
+                                        _lib.stream_ptr()), "digat_linear_f32x3")
+    finally:
+        L.digat_set_gemm_format(prev)
+    _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K, _lib.stream_ptr()),
+               "digat_linear_f32")
+    torch.cuda.synchronize()
+    e16 = np.abs(y16.cpu().numpy().astype(np.float64) - want)
+    e32 = np.abs(y32.cpu().numpy().astype(np.float64) - want)
+    print(f"\n[fp16x3 {M}x{N}x{K} x{scale}] mean {e16.mean():.3e} (fp32 chain {e32.mean():.3e}), max {e16.max():.3e} ({e32.max():.3e})")
+    assert np.isfinite(e16).all()
+    assert e16.mean() <= 1.1 * e32.mean() + 1e-9 and e16.max() <= 1.1 * e32.max() + 1e-8

@@ -124,7 +124,7 @@ def test_linear_bf16x6_is_fp32_grade(M, N, K):
 
 
 def test_projection_modes_agree():
-    """Whole encoder with the node projections on the fp32 MFMA path vs the bf16x6 path."""
+    """Whole encoder with the node projections on the fp32 MFMA path vs the two split-operand formats; what "auto" picks."""
     from digat_amd import synthetic
     B, N, H, C, d, L = 64, 10, 50, 17, 400, 3
     state = synthetic.make_state_dict(d, C, L, seed=13, bias_std=0.05)
@@ -133,12 +133,19 @@ def test_projection_modes_agree():
             "user_category_mask", "user_category_indices")
     enc = make_encoder(state, N, H, C, d, L)
     outs = {}
-    for mode in ("fp32", "bf16x6"):
+    assert enc.projection_mode == "auto" and enc.resolved_projection_mode() == "fp16x3"      # Xavier-sized weights: far below 32
+    for mode in ("fp32", "bf16x6", "fp16x3"):
         enc.projection_mode = mode
         with torch.no_grad():
             outs[mode] = enc(*(batch[k] for k in keys))
-    close(outs["bf16x6"][0], outs["fp32"][0], "news ctx, bf16x6 vs fp32")
-    close(outs["bf16x6"][1], outs["fp32"][1], "user ctx, bf16x6 vs fp32")
+    for mode in ("bf16x6", "fp16x3"):
+        close(outs[mode][0], outs["fp32"][0], f"news ctx, {mode} vs fp32")
+        close(outs[mode][1], outs["fp32"][1], f"user ctx, {mode} vs fp32")
+    # weights beyond fp16x3's range: "auto" falls back to the range-free format
+    enc.projection_mode = "auto"
+    with torch.no_grad():
+        enc.featureAffine.weight[0, 0] = 40.0
+    assert enc.resolved_projection_mode() == "bf16x6"
 
 
 @pytest.mark.parametrize("name", ["tiny.npz", "edges.npz"])
