@@ -81,6 +81,7 @@ class DIGAT(GraphEncoder):
         # "auto" (default) = "fp16x3" when every projected weight is below 32 in magnitude, else "bf16x6" (no range limit)
         self.projection_mode = "auto"
         self._resolved_pm = None
+        self.corpus_activation_max = None  # max |news representation| of the corpus, set by util.prepare_news_side
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
         self.user_xattn_mode = "auto"
@@ -204,9 +205,14 @@ class DIGAT(GraphEncoder):
         ws = [m.weight for g in ("news", "user") for f in ("W", "ffn1", "ffn2") for m in getattr(self, f"{g}_graph_attention_{f}")]
         ws.append(self.featureAffine.weight)
         key = tuple((w.data_ptr(), w._version) for w in ws)
+        key += (self.corpus_activation_max,)
         if self._resolved_pm is None or self._resolved_pm[0] != key:
             wmax = float(torch.stack([w.detach().abs().max() for w in ws]).max())
-            self._resolved_pm = (key, "fp16x3" if wmax < 32.0 else "bf16x6")       # nan compares false: bf16x6
+            amax = self.corpus_activation_max
+            # weights below 32 (the format holds 63) and, where util.prepare_news_side has seen the corpus, news representations
+            # below 256 (node features grow by at most one relu(alpha h) per layer; the format holds 4094); nan compares false
+            ok = wmax < 32.0 and (amax is None or amax < 256.0)
+            self._resolved_pm = (key, "fp16x3" if ok else "bf16x6")
         return self._resolved_pm[1]
 
     def _flags(self) -> int:

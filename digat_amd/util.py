@@ -117,6 +117,9 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
             per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
             hint["news"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
         encoder.corpus_xattn_hint = hint          # in force while the encoder's own setting is "auto"
+    if hasattr(encoder, "corpus_activation_max") and dc.news_embedding.numel() > 0:
+        # the range of the node features the projections will see ("auto" projection format: graphEncoders.resolved_projection_mode)
+        encoder.corpus_activation_max = float(dc.news_embedding.abs().max())
     dc.SA_news_representations = dc.news_embedding.index_select(0, dc.news_node_ID.flatten()).view(news_num, N, d)
     c_n0 = torch.empty((news_num, d), dtype=torch.float32, device=dc.news_embedding.device)
     with torch.no_grad():

@@ -146,6 +146,11 @@ def test_projection_modes_agree():
     with torch.no_grad():
         enc.featureAffine.weight[0, 0] = 40.0
     assert enc.resolved_projection_mode() == "bf16x6"
+    with torch.no_grad():
+        enc.featureAffine.weight[0, 0] = 0.01
+    assert enc.resolved_projection_mode() == "fp16x3"
+    enc.corpus_activation_max = 1000.0             # ... and so do news representations beyond 256 (util.prepare_news_side reports them)
+    assert enc.resolved_projection_mode() == "bf16x6"
 
 
 @pytest.mark.parametrize("name", ["tiny.npz", "edges.npz"])
