@@ -144,6 +144,7 @@ _SIGNATURES = {
     "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 5 + [_f, C.c_size_t, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
 }
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 EXPORTED = tuple(_SIGNATURES)

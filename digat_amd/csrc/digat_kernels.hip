@@ -44,12 +44,13 @@ static struct {
     double* work;
     unsigned long long* rows_dev;      // [kinds] row-list GEMM launches add the rows they actually processed (device counters)
     double flops_per_row[16]; double rows_nominal[16];
-} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}};
+    unsigned kind_mask;                // only launches of these kinds are bracketed (digat_profile_set_kinds)
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}, ~0u};
 
 struct ProfScope {
     hipStream_t st; int slot;
     ProfScope(int kind, double work, hipStream_t s) : st(s), slot(-1) {
-        if (g_prof.enabled && g_prof.used < g_prof.cap) {
+        if (g_prof.enabled && ((g_prof.kind_mask >> kind) & 1u) && g_prof.used < g_prof.cap) {
             slot = g_prof.used++;
             g_prof.kind[slot] = kind; g_prof.work[slot] = work;
             (void)hipEventRecord(g_prof.ev[2 * slot], st);
@@ -1031,6 +1032,14 @@ int digat_profile_pause(int paused) {
     if (!g_prof.ev) return DIGAT_ERR_ARG;
     g_prof.enabled = paused ? 0 : 1;
     return DIGAT_OK;
+}
+
+// Which kernel kinds get their two events: every event pair is a pair of marker packets in the launch's queue and costs the
+// overlapped encoder about 1 % of a step per 10 pairs; a measurement that only needs the dominant kernels says so.
+int digat_profile_set_kinds(unsigned mask) {
+    const unsigned prev = g_prof.kind_mask;
+    g_prof.kind_mask = mask;
+    return (int)prev;
 }
 
 int digat_profile_start(int max_launches) {

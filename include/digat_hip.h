@@ -486,6 +486,8 @@ enum {
     DIGAT_KERNEL_KINDS = 7
 };
 int digat_profile_start(int max_launches);
+/* bit k set = launches of kind k are recorded (default: all).  Returns the previous mask. */
+int digat_profile_set_kinds(unsigned mask);
 int digat_profile_pause(int paused);   /* between start and stop: 1 = launches are not recorded, 0 = recorded again (sampling) */
 /* after digat_profile_stop: rows processed / rows nominal over the row-list node-projection launches of the profiled
  * region (the encoder leaves the user-graph nodes that cannot reach its outputs out of the projections of
