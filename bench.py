@@ -289,6 +289,7 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         sc.kept = []
     D.fence()
     profiled_steps = rows_done = 0
+    _lib.lib().digat_profile_marker(1, _lib.stream_ptr())       # landmark for tools/trace_region.py: the timed region begins
     t0 = time.perf_counter()
     for i in range(steps):
         sampled = with_profile and i % PROFILE_EVERY == 0
@@ -307,6 +308,7 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         sc.kept = None
     D.fence()
     elapsed = time.perf_counter() - t0
+    _lib.lib().digat_profile_marker(2, _lib.stream_ptr())       # ... and ends
     out = types.SimpleNamespace(elapsed=elapsed, rows_done=rows_done, profiled_steps=profiled_steps, revisited=sc.revisited,
                                 batches_in_flight=sc.nlanes,
                                 prof=None, prof_iso=None, live_fraction=None, iso_steps=0,

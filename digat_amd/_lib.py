@@ -145,6 +145,7 @@ _SIGNATURES = {
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
+    "digat_profile_marker": (C.c_int, [C.c_int, _f]),
 }
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 EXPORTED = tuple(_SIGNATURES)

@@ -1034,6 +1034,16 @@ int digat_profile_pause(int paused) {
     return DIGAT_OK;
 }
 
+// A one-thread kernel whose only purpose is to be visible in a kernel trace (rocprofv3 --kernel-trace): bench.py launches one
+// at each end of its timed region, so that per-kernel averages of exactly that region can be cut out of the trace
+// (tools/trace_region.py) and held against the library's own event timings.
+__global__ void digat_region_marker_kernel(int id, int* sink) { if (sink && id < 0) *sink = id; }
+int digat_profile_marker(int id, void* stream) {
+    hipLaunchKernelGGL(digat_region_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, id, (int*)nullptr);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
 // Which kernel kinds get their two events: every event pair is a pair of marker packets in the launch's queue and costs the
 // overlapped encoder about 1 % of a step per 10 pairs; a measurement that only needs the dominant kernels says so.
 int digat_profile_set_kinds(unsigned mask) {

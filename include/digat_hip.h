@@ -486,6 +486,8 @@ enum {
     DIGAT_KERNEL_KINDS = 7
 };
 int digat_profile_start(int max_launches);
+/* launches a one-thread kernel (digat_region_marker_kernel) on `stream`: a landmark in a rocprofv3 kernel trace */
+int digat_profile_marker(int id, void* stream);
 /* bit k set = launches of kind k are recorded (default: all).  Returns the previous mask. */
 int digat_profile_set_kinds(unsigned mask);
 int digat_profile_pause(int paused);   /* between start and stop: 1 = launches are not recorded, 0 = recorded again (sampling) */

@@ -11,7 +11,9 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 B="python3 $ROOT/bench.py --extra-steps 0 --cpu-rows 0 --steps 30"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_traced.json 2> $OUT/trace.err
+# the traced run records its event pairs on EVERY step of the timed region, so that the library's averages and the trace's
+# (tools/trace_region.py, below) are over the same launches
+DIGAT_BENCH_PROFILE_EVERY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_sq.err
@@ -24,6 +26,16 @@ python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma --match gemm_bf16x6s > $OUT
 python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write --match xattn_sparse > $OUT/sparse_pmc.txt 2>&1
 python3 tools/pmc_table.py $OUT/pmc_fetch_stream $OUT/pmc_write_stream --match xattn_stream > $OUT/stream_pmc.txt 2>&1
 python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
+# per-kernel averages of the traced run's TIMED REGION only (between bench.py's two marker kernels), next to that run's own line
+python3 tools/trace_region.py $OUT/trace/t_kernel_trace.csv > $OUT/timed_region_kernels.txt 2>&1
+python3 - >> $OUT/timed_region_kernels.txt 2>&1 <<PYEOF
+import json
+j = json.loads(open("$OUT/bench_traced.json").read().strip().splitlines()[-1])
+r, x = j["roofline"], j["roofline_xattn"]
+print()
+print("the same run's own line (library events, sampled steps): ms_per_step %.4f; %s avg_launch_ms %.4f over %d launches; "
+      "xattn avg_launch_ms %.4f over %d launches" % (j["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["launches"], x["avg_launch_ms"], x["launches"]))
+PYEOF
 # keep what is merged back small: drop the raw per-dispatch tables
 find $OUT -name "*counter_collection.csv" -size +1M -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
