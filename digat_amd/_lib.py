@@ -32,6 +32,12 @@ class MsaParams(C.Structure):
                                              "qkv_wsplit", "a1_wsplit")])
 
 
+class GatherJob(C.Structure):
+    """digat_gather_job (include/digat_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("rows", C.c_int64),
+                ("idx", C.c_void_p), ("idx2", C.c_void_p), ("inner", C.c_int64)]
+
+
 class Params(C.Structure):
     _fields_ = ([("d", C.c_int32), ("depth", C.c_int32), ("category_num", C.c_int32), ("flags", C.c_int32)]
                 + [(k, _f) for k in ("topic_node_embedding", "cand_K", "cand_Q", "cand_bQ",
@@ -70,6 +76,7 @@ _SIGNATURES = {
     "digat_set_live_row_skipping": (C.c_int, [C.c_int]),
     "digat_set_staged_xattn": (C.c_int, [C.c_int]),
     "digat_set_train_precision": (C.c_int, [C.c_int]),
+    "digat_gather_tables": (C.c_int, [C.POINTER(GatherJob), C.c_int, _f]),
     "digat_set_gemm_format": (C.c_int, [C.c_int]),
     "digat_get_gemm_format": (C.c_int, []),
     "digat_profile_live_row_fraction": (C.c_double, []),

@@ -249,6 +249,28 @@ static int launch_split(const float* w0, const float* w1, const float* w2, int n
     return DIGAT_OK;
 }
 
+int digat_gather_tables(const digat_gather_job* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 0 || njobs > GATHER_MAX_JOBS) return DIGAT_ERR_ARG;
+    if (njobs == 0) return DIGAT_OK;
+    GatherTableJobs all;
+    memset(&all, 0, sizeof(all));
+    long most = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const digat_gather_job& j = jobs[k];
+        if (j.rows < 0 || j.row_bytes <= 0 || (j.rows > 0 && (!j.src || !j.dst || !j.idx)) || (j.idx2 && j.inner <= 0)) return DIGAT_ERR_ARG;
+        all.job[k] = j;
+        if (!j.idx2) all.job[k].inner = 1;
+        const long units = (j.row_bytes & 15) == 0 ? j.rows * (j.row_bytes >> 4) : j.rows * j.row_bytes;
+        if (units > most) most = units;
+    }
+    if (most == 0) return DIGAT_OK;
+    long bx = (most + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(gather_tables_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, all);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
 int digat_set_gemm_format(int format) {
     const int prev = g_gemm_format;
     g_gemm_format = format ? 1 : 0;

@@ -470,6 +470,19 @@ size_t digat_embedding_bwd_workspace_bytes(int64_t M, int dm);
 int digat_embedding_bwd(const float* row_grad, int64_t ld_row_grad, const int32_t* order, const int32_t* sorted_tokens, int64_t M, int dm,
                         float* table_grad, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- batch assembly (the device-side counterpart of MIND_dataset.py's __getitem__ + collate) ------------------
+ * All table gathers of one scoring batch in one launch.  Job k copies `rows` rows of `row_bytes` bytes: dst row r = src row
+ * idx[r] (idx2 == NULL, inner = 1) or src row idx2[idx[r / inner] * inner + r % inner] (two-level: e.g. the representation of
+ * the r % H-th history item of impression idx[r / H], idx2 = the [impressions, H] history table).  `jobs` is a HOST array
+ * (njobs <= 24), copied into the launch; every pointer inside is a device pointer. */
+typedef struct digat_gather_job {
+    const void* src; void* dst;
+    int64_t row_bytes, rows;
+    const int64_t* idx; const int64_t* idx2;
+    int64_t inner;
+} digat_gather_job;
+int digat_gather_tables(const digat_gather_job* jobs, int njobs, void* stream);
+
 /* ---- measurement aid (not on the reference's surface): per-kernel HIP-event timing ---------------
  * Between start and stop every kernel launch of this library is bracketed by two events recorded
  * on the stream it is launched on.  stop() synchronises and returns, per kernel kind, the summed

@@ -898,3 +898,39 @@ def test_per_news_caches_follow_the_weights():
     fresh = util.DeviceCorpus.from_numpy(corpus, _dev())
     s2_fresh, _ = util.compute_scores(model, fresh, 512, labels=corpus.row_label)
     assert np.array_equal(s2, s2_fresh) and not np.allclose(s1, s2)
+
+
+def test_gather_tables_equals_index_select():
+    """digat_gather_tables (all table gathers of a batch in one launch) against torch.index_select: 16-byte-word rows, byte rows
+    (bool tables, odd sizes), a two-level job (rows read through a history table), zero rows."""
+    from digat_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    I, H, n_news, d = 37, 10, 200, 36
+    emb = torch.randn(n_news, d, generator=g).to(dev)
+    hist = torch.randint(0, n_news, (I, H), generator=g).to(dev)
+    graph = (torch.rand(I, 7, 7, generator=g) < 0.3).to(dev)               # 49-byte rows: the byte path
+    odd = torch.randn(I, 5, generator=g).to(dev)                          # 20-byte rows
+    uniq = torch.tensor([3, 0, 36, 3, 17], dtype=torch.int64, device=dev)
+    cand = torch.randint(0, n_news, (23,), generator=g).to(dev)
+    out_hist = torch.empty(5, H, dtype=torch.int64, device=dev)
+    out_rep = torch.empty(5 * H, d, device=dev)
+    out_graph = torch.empty(5, 7, 7, dtype=torch.bool, device=dev)
+    out_odd = torch.empty(5, 5, device=dev)
+    out_cand = torch.empty(23, d, device=dev)
+    out_none = torch.empty(0, d, device=dev)
+    J = _lib.GatherJob
+    jobs = [J(hist.data_ptr(), out_hist.data_ptr(), H * 8, 5, uniq.data_ptr(), 0, 1),
+            J(emb.data_ptr(), out_rep.data_ptr(), d * 4, 5 * H, uniq.data_ptr(), hist.data_ptr(), H),
+            J(graph.data_ptr(), out_graph.data_ptr(), 49, 5, uniq.data_ptr(), 0, 1),
+            J(odd.data_ptr(), out_odd.data_ptr(), 20, 5, uniq.data_ptr(), 0, 1),
+            J(emb.data_ptr(), out_cand.data_ptr(), d * 4, 23, cand.data_ptr(), 0, 1),
+            J(emb.data_ptr(), out_none.data_ptr(), d * 4, 0, cand.data_ptr(), 0, 1)]
+    arr = (J * len(jobs))(*jobs)
+    _lib.check(_lib.lib().digat_gather_tables(arr, len(jobs), _lib.stream_ptr()), "digat_gather_tables")
+    torch.cuda.synchronize()
+    assert torch.equal(out_hist, hist[uniq])
+    assert torch.equal(out_rep, emb[hist[uniq].reshape(-1)])
+    assert torch.equal(out_graph, graph[uniq])
+    assert torch.equal(out_odd, odd[uniq])
+    assert torch.equal(out_cand, emb[cand])
