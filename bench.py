@@ -94,6 +94,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(args) -> None:
+    """``python bench.py --gpus N`` (N > 1) without a launcher: start ``torch.distributed.run`` with one rank per GPU as a CHILD
+    process and relay its output and exit code.  This parent never touches the GPU (no HIP call is made before this point:
+    replacing or forking a process that has initialised the GPU is what the GPU boxes forbid), so the ranks start clean.
+    The launcher path of the task's contract (``python -m torch.distributed.run ... bench.py --gpus N``) sets WORLD_SIZE and
+    never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                    # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this image
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:6])} ... as a child process", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 class Dist:
     """The control plane of a run: world, rank, barrier, reductions of timing scalars."""
 
@@ -102,8 +121,8 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+                self_launch(args)                   # does not return
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
         # test hook (one-GPU boxes): DIGAT_BENCH_TEST_SHARED_GPU=1 puts every rank on cuda:0 and runs the collectives over gloo
@@ -115,7 +134,11 @@ class Dist:
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo" if self.shared_gpu else "nccl")          # nccl = RCCL on ROCm
+            self.backend = "gloo" if self.shared_gpu else "nccl"                   # nccl = RCCL on ROCm
+            dist.init_process_group(self.backend)
+            self.world_seen = dist.get_world_size()
+        else:
+            self.backend, self.world_seen = None, 1
 
     def fence(self):
         torch.cuda.synchronize()
@@ -214,7 +237,11 @@ class Scorer:
         if self.pipe is None and self.order is None or k - self.base >= self.CHUNK:
             self.base = k
             self.order = [(((k + j) % self.nbatches) * B, min(((k + j) % self.nbatches) * B + B, W.dc.rows)) for j in range(self.CHUNK)]
-            self.pipe = None if self.per_row else util.GroupedBatchPipeline(W.dc, self.order, self.imp_host)
+            if self.pipe is not None:             # the old pipeline's buffers return to the allocator: every lane must be done with them
+                self.join()
+                with torch.cuda.stream(self.lanes[0]):
+                    self.pipe.drain()
+            self.pipe = None if self.per_row else util.GroupedBatchPipeline(W.dc, self.order, self.imp_host, nsets=len(self.lanes))
             for extra in self.lanes[1:]:
                 extra.wait_stream(self.lanes[0])
         s, e = self.order[k - self.base]
@@ -565,7 +592,10 @@ def workload_config(W, args, D):
             "device_table_bytes": W.table_bytes,
             "mean_candidates_per_impression": round(W.mean_cand, 3),
             "parallelism": f"dp{D.world} (row shards, no data-path collective"
-                           + ("; one all_gather of the scores closes the timed region)" if D.world > 1 else ")")}
+                           + ("; one all_gather of the scores closes the timed region)" if D.world > 1 else ")"),
+            # the collective backend of this run and the number of ranks it rendezvoused ("nccl" is RCCL on ROCm; "gloo" only
+            # under the one-GPU test hook DIGAT_BENCH_TEST_SHARED_GPU)
+            "backend": D.backend, "ranks_in_process_group": D.world_seen}
 
 
 def main():

@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIGAT_HIP_LIB") or os.path.join(_HERE, "lib", "libdigat_hip.so")
 DIGAT_MAX_DEPTH = 16
 DIGAT_MAX_NODES = 128
+GEMM_BF16X6, GEMM_F16X3 = 0, 1          # operand format of a split weight image (include/digat_hip.h)
+PARAMS_GEMM_F16X3 = 64                  # digat_params.flags: the block's wsplit images are GEMM_F16X3
 
 _f = C.c_void_p  # every device pointer crosses as void*
 
@@ -46,7 +48,7 @@ class Params(C.Structure):
                                      "userAtt_K", "userAtt_Q", "userAtt_bQ")]
                 + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)]
                 + [(k, _f) for k in ("cand_fold_W", "cand_fold_b", "user_news_fold_W", "user_news_fold_b",
-                                     "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit")])
+                                     "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit", "range_flag")])
 
 
 class DigatHipError(RuntimeError):
@@ -77,8 +79,6 @@ _SIGNATURES = {
     "digat_set_staged_xattn": (C.c_int, [C.c_int]),
     "digat_set_train_precision": (C.c_int, [C.c_int]),
     "digat_gather_tables": (C.c_int, [C.POINTER(GatherJob), C.c_int, _f]),
-    "digat_set_gemm_format": (C.c_int, [C.c_int]),
-    "digat_get_gemm_format": (C.c_int, []),
     "digat_profile_live_row_fraction": (C.c_double, []),
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
     "digat_gat_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
@@ -109,9 +109,9 @@ _SIGNATURES = {
     "digat_user_project0": (C.c_int, [C.POINTER(Params), _f, _f, C.c_int, _f]),
     "digat_news_project0": (C.c_int, [C.POINTER(Params), _f, _f, C.c_int, C.c_int, _f]),
     "digat_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "digat_split_proj_weights": (C.c_int, [_f, _f, _f, C.c_int, _f, _f]),
-    "digat_split_weights": (C.c_int, [_f, C.c_int, C.c_int, _f, _f]),
-    "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f]),
+    "digat_split_proj_weights": (C.c_int, [_f, _f, _f, C.c_int, _f, C.c_int, _f]),
+    "digat_split_weights": (C.c_int, [_f, C.c_int, C.c_int, _f, C.c_int, _f]),
+    "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f]),
     "digat_fold_workspace_bytes": (C.c_size_t, [C.c_int]),
     "digat_fold_attention": (C.c_int, [_f] * 5 + [C.c_int, _f, C.c_size_t, _f]),
     "digat_linear_bwd_input": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f]),

@@ -20,7 +20,9 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "../../include/digat_hip.h"
 
@@ -160,7 +162,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       float* out, float* alpha_out, int B, int n, int d, void* workspace, hipStream_t st,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
-                      int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0) {
+                      int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0,
+                      int gemm_format = 0, unsigned* range_flag = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -172,7 +175,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     g.w[1] = F1; g.bias[1] = nullptr; g.y[1] = P;
     g.w[2] = F2; g.bias[2] = nullptr; g.y[2] = Q;
     g.nsegs = 3;
-    g.wsplit = (const unsigned short*)wsplit;          // non-NULL: bf16x6 on the bf16 matrix cores
+    g.wsplit = (const unsigned short*)wsplit;          // non-NULL: split operands on the bf16 / fp16 matrix cores
+    g.format = gemm_format; g.range_flag = range_flag;
     g.radd = r_given; g.radd_seg = 1; g.rows_per_b = n; // P' = K3 + K1: the reference's left-to-right order
     g.x3_segs = pq_x3 ? 6 : 0;                          // DIGAT_PROJ_PQ_X3: P and Q (segments 1, 2) with three products
     // DIGAT_PQ_BF16 (pq_mode & 1): P' and Q stored in bf16, read by the wave-per-centre sparse kernel; & 2: one product for them
@@ -238,13 +242,16 @@ size_t digat_split_weights_bytes(int rows, int K) {
     return (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;       // one 15 KB image per (80-row strip, K tile)
 }
 
+// format: DIGAT_GEMM_BF16X6 (three bf16 pieces; what every training entry uses) or DIGAT_GEMM_F16X3 (two scaled fp16 pieces)
 static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st,
-                        int transposed = 0) {
+                        int transposed = 0, int format = 0) {
+    if (format != 0 && format != 1) return DIGAT_ERR_ARG;
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    wsplit_note(wsplit, format);
     hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit, transposed,
-                       gemm_format_f16() ? 2 : 3);
+                       format == 1 ? 2 : 3);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
@@ -271,41 +278,30 @@ int digat_gather_tables(const digat_gather_job* jobs, int njobs, void* stream) {
     return DIGAT_OK;
 }
 
-int digat_set_gemm_format(int format) {
-    const int prev = g_gemm_format;
-    g_gemm_format = format ? 1 : 0;
-    return prev;
-}
-int digat_get_gemm_format(void) { return g_gemm_format; }
-
-int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream) {
+int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, int format, void* stream) {
     if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;
-    return launch_split(W, F1, F2, d, 3, d, wsplit, (hipStream_t)stream);
+    return launch_split(W, F1, F2, d, 3, d, wsplit, (hipStream_t)stream, 0, format);
 }
 
-int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream) {
+int digat_split_weights(const float* W, int N, int K, void* wsplit, int format, void* stream) {
     if (!W || !wsplit || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
-    return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream);
+    return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream, 0, format);
 }
 
 // BASELINE configs[4], training half: the >= 2048-row GEMMs of the training path (projections, featureAffine, input
 // gradients) with ONE bf16 product per fp32 product — plain bf16 mixed precision: fp32 master weights and activations, bf16
 // matrix-core operands, fp32 accumulation — instead of the six of the fp32-grade split (the >= 2048-row weight gradients included: gemm_tn_bf16x6_kernel<true>).
-static int g_train_bf16 = 0;
-int digat_set_train_precision(int bf16) {
-    const int prev = g_train_bf16;
-    g_train_bf16 = bf16 ? 1 : 0;
-    return prev;
-}
+static std::atomic<int> g_train_bf16{0};      // set once per training run (Trainer.__init__); read by every training GEMM
+int digat_set_train_precision(int bf16) { return g_train_bf16.exchange(bf16 ? 1 : 0); }
 
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
-                       int M, int N, int K, void* wsplit, void* stream) {
+                       int M, int N, int K, void* wsplit, int format, void* stream) {
     if (!x || !w || !y || !wsplit || M < 0 || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
     if (K % 8 || ldx % 4 || N % 80) return DIGAT_ERR_SHAPE;
-    const int rcs = launch_split(w, w, w, N, 1, K, wsplit, (hipStream_t)stream);
+    const int rcs = launch_split(w, w, w, N, 1, K, wsplit, (hipStream_t)stream, 0, format);
     if (rcs) return rcs;
     GemmArgs g = gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0);
-    g.wsplit = (const unsigned short*)wsplit;
+    g.wsplit = (const unsigned short*)wsplit; g.format = format;
     if (g_train_bf16) g.x1_segs = 7;
     if (M < 2048) return DIGAT_ERR_SHAPE;      // the bf16x6 kernel serves the big projections only
     return launch_gemm(g, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
@@ -484,6 +480,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
+    const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;       // the format every wsplit image of `p` was split in
+    unsigned* const rflag = fmt ? (unsigned*)p->range_flag : nullptr;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
     float* T2 = (float*)((char*)cws + s2);        // after featureAffine
@@ -507,7 +505,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
-        g.wsplit = (const unsigned short*)p->featureAffine_wsplit;       // non-NULL: bf16x6
+        g.wsplit = (const unsigned short*)p->featureAffine_wsplit;       // non-NULL: split operands on the matrix cores
+        g.format = fmt; g.range_flag = rflag;
         if (bucket_idx && gemm_is_bf16x6(g)) { g.rowidx = bucket_idx; g.nrows_dev = nbuckets_dev; }   // unmasked buckets only
         e = launch_gemm(g, sq);
         if (e) return e;
@@ -605,6 +604,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gp.m_dispatch = 1 << 30;       // always the large-M kernel: a row's bits then do not depend on the batch it sits in
                                        // (digat_news_project0 makes the same launch per news, once)
         gp.wsplit = (const unsigned short*)ln.wsplit;
+        gp.format = fmt; gp.range_flag = rflag;
         return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
     };
     // layer 0 of grouped rows: every row of a group has the same user nodes, so the G groups are projected once
@@ -646,6 +646,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         gg.nsegs = 3;
         gg.x3_segs = pq_x3 ? 6 : 0;
         gg.wsplit = (const unsigned short*)lu.wsplit;
+        gg.format = fmt; gg.range_flag = rflag;
         gg.m_dispatch = B * U;                              // the kernel the per-row path would pick: same bits
         return launch_gemm(gg, sq, DIGAT_KERNEL_PROJ);
     };
@@ -756,7 +757,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) : 0,
                             // after the last layer only the history rows are read (the user context's topic pooling, :124):
                             // the topic nodes' own Eq. 8 is not computed there (wave-per-centre sparse kernel)
-                            (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0);
+                            (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0, fmt, rflag);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
@@ -777,7 +778,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             nullptr, nullptr, nullptr, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
                             nullptr, pq_x3, nullptr, 0,
                             // the news graph's P' always carries K3 from the GEMM epilogue: bf16 storage applies at every layer
-                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0));
+                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0), 0, fmt, rflag);
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
@@ -909,11 +910,15 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         // both graph updates read the PREVIOUS contexts (:194-195)
         rc = launch_gemm(gemm_plain(out_user, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), st);
         if (rc) return rc;
-        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit);
+        const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;
+        unsigned* const rflag = fmt ? (unsigned*)p->range_flag : nullptr;
+        rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws, st, ln.wsplit,
+                        nullptr, nullptr, nullptr, DIGAT_XATTN_DENSE, nullptr, 0, nullptr, 0, 0, 0, fmt, rflag);
         if (rc) return rc;
         rc = launch_gemm(gemm_plain(out_news, d, lu.F3, lu.b3, r_user, d, B, d, d, 0), st);
         if (rc) return rc;
-        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit);
+        rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
+                        nullptr, nullptr, nullptr, DIGAT_XATTN_DENSE, nullptr, 0, nullptr, 0, 0, 0, fmt, rflag);
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
         // c_n += news context (:196); c_u += user context with the UPDATED c_n (:197)
@@ -1023,6 +1028,7 @@ int digat_user_project0(const digat_params* p, const float* X, float* hpq, int M
     gg.nsegs = 3;
     gg.x3_segs = (p->flags & DIGAT_PROJ_PQ_X3) ? 6 : 0;
     gg.wsplit = (const unsigned short*)lu.wsplit;
+    gg.format = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0; gg.range_flag = gg.format ? (unsigned*)p->range_flag : nullptr;
     gg.m_dispatch = 1 << 30;                                               // the large-M kernel whatever M is (C topic rows)
     return launch_gemm(gg, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
@@ -1041,6 +1047,7 @@ int digat_news_project0(const digat_params* p, const float* Xn, float* hpq, int 
     gp.nsegs = 3;
     gp.x3_segs = (p->flags & DIGAT_PROJ_PQ_X3) ? 6 : 0;
     gp.wsplit = (const unsigned short*)ln.wsplit;
+    gp.format = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0; gp.range_flag = gp.format ? (unsigned*)p->range_flag : nullptr;
     gp.m_dispatch = 1 << 30;
     return launch_gemm(gp, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }

@@ -81,6 +81,8 @@ class DIGAT(GraphEncoder):
         # "auto" (default) = "fp16x3" when every projected weight is below 32 in magnitude, else "bf16x6" (no range limit)
         self.projection_mode = "auto"
         self._resolved_pm = None
+        self._range_flag = None            # device word raised by the fp16x3 GEMMs on out-of-range activations (range_flag())
+        self.range_fallback = False        # set by util.compute_scores after such a run: "auto" then resolves to bf16x6
         self.corpus_activation_max = None  # max |news representation| of the corpus, set by util.prepare_news_side
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
@@ -125,10 +127,10 @@ class DIGAT(GraphEncoder):
         return super()._apply(fn, *args, **kwargs)
 
     def _params(self) -> "_lib.Params":
-        # the matrix-core operand format is a process-wide library setting: every call of this encoder sets its own
-        # ("fp16x3": two fp16 pieces, three products; everything else: three bf16 pieces, six products)
+        # the matrix-core operand format ("fp16x3": two fp16 pieces, three products; everything else: three bf16 pieces, six
+        # products) is a property of the split images made below and travels in P.flags: nothing process-wide
         pm = self.resolved_projection_mode()
-        _lib.lib().digat_set_gemm_format(1 if pm == "fp16x3" else 0)
+        fmt = _lib.GEMM_F16X3 if pm == "fp16x3" else _lib.GEMM_BF16X6
         ptrs = tuple(p.data_ptr() for p in self.parameters())
         if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
             # the Eq. 8 variant only selects kernels (P.flags): it never invalidates the split weights or the folded
@@ -178,15 +180,17 @@ class DIGAT(GraphEncoder):
                     _lib.check(L_.digat_split_proj_weights(
                         getattr(self, f"{g}_graph_attention_W")[i].weight.data_ptr(),
                         getattr(self, f"{g}_graph_attention_ffn1")[i].weight.data_ptr(),
-                        getattr(self, f"{g}_graph_attention_ffn2")[i].weight.data_ptr(), d, buf.data_ptr(),
+                        getattr(self, f"{g}_graph_attention_ffn2")[i].weight.data_ptr(), d, buf.data_ptr(), fmt,
                         _lib.stream_ptr()), "digat_split_proj_weights")
                     arr[i].wsplit = buf.data_ptr()
                     P._splits.append(buf)
             buf = torch.empty(L_.digat_split_weights_bytes(d, d), dtype=torch.uint8, device=self.topic_node_embedding.device)
-            _lib.check(L_.digat_split_weights(self.featureAffine.weight.data_ptr(), d, d, buf.data_ptr(), _lib.stream_ptr()),
+            _lib.check(L_.digat_split_weights(self.featureAffine.weight.data_ptr(), d, d, buf.data_ptr(), fmt, _lib.stream_ptr()),
                        "digat_split_weights")
             P.featureAffine_wsplit = buf.data_ptr()
             P._splits.append(buf)
+            if fmt == _lib.GEMM_F16X3:           # one device word the fp16x3 GEMMs raise when an activation leaves the format's range
+                P.range_flag = self.range_flag().data_ptr()
         # inference: fold the key projections into the query weights once per weight version
         P._folds = None
         if not self.training:
@@ -204,16 +208,39 @@ class DIGAT(GraphEncoder):
             return "bf16x6"
         ws = [m.weight for g in ("news", "user") for f in ("W", "ffn1", "ffn2") for m in getattr(self, f"{g}_graph_attention_{f}")]
         ws.append(self.featureAffine.weight)
-        key = tuple((w.data_ptr(), w._version) for w in ws)
-        key += (self.corpus_activation_max,)
+        key = tuple((w.data_ptr(), w._version) for w in ws + [self.topic_node_embedding])
+        key += (self.corpus_activation_max, self.range_fallback)
         if self._resolved_pm is None or self._resolved_pm[0] != key:
-            wmax = float(torch.stack([w.detach().abs().max() for w in ws]).max())
             amax = self.corpus_activation_max
-            # weights below 32 (the format holds 63) and, where util.prepare_news_side has seen the corpus, news representations
-            # below 256 (node features grow by at most one relu(alpha h) per layer; the format holds 4094); nan compares false
-            ok = wmax < 32.0 and (amax is None or amax < 256.0)
+            # fp16x3 needs a driver that looks at the range flag after the run (util.compute_scores / score_rows do, and fall back
+            # to bf16x6): "auto" therefore picks it only once util.prepare_news_side has seen the corpus — direct forward /
+            # inference calls get the range-free bf16x6.  Then: weights below 32 (the format holds 63), the topic nodes and the
+            # corpus's news representations below 256 (the format holds 4094; what the features of layers >= 1 grow to is
+            # checked on the device, by the GEMM itself); nan compares false
+            ok = amax is not None and not self.range_fallback
+            if ok:
+                wmax = float(torch.stack([w.detach().abs().max() for w in ws]).max())
+                tmax = float(self.topic_node_embedding.detach().abs().max())
+                ok = wmax < 32.0 and amax < 256.0 and tmax < 256.0
             self._resolved_pm = (key, "fp16x3" if ok else "bf16x6")
         return self._resolved_pm[1]
+
+    def range_flag(self) -> torch.Tensor:
+        """The device word the fp16x3 GEMMs OR 1 into when an activation reaches the format's range (digat_params.range_flag)."""
+        dev = self.topic_node_embedding.device
+        if self._range_flag is None or self._range_flag.device != dev:
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._range_flag
+
+    def range_overflowed(self, reset: bool = True) -> bool:
+        """True when an fp16x3 GEMM of this encoder has seen an activation at or beyond the format's range since the last
+        reset (one host synchronisation: call it once per scoring run, as util.compute_scores does)."""
+        if self._range_flag is None:
+            return False
+        hit = bool(int(self._range_flag.item()))
+        if reset and hit:
+            self._range_flag.zero_()
+        return hit
 
     def _flags(self) -> int:
         """digat_params.flags (include/digat_hip.h): Eq. 8 variant of the user graph (bits 0-1), DIGAT_PROJ_PQ_X3 (bit 2),
@@ -223,7 +250,8 @@ class DIGAT(GraphEncoder):
                 | (4 if pm in ("bf16x6-pq3", "pq-bf16") else 0)
                 | (8 if self.resolved_xattn_mode("news") == "sparse" else 0)
                 | (16 if pm in ("pq-bf16", "pq-bf16-x1") else 0)         # DIGAT_PQ_BF16: P', Q of Eq. 8 stored in bf16
-                | (32 if pm == "pq-bf16-x1" else 0))                     # DIGAT_PQ_X1: ... and computed with one bf16 product
+                | (32 if pm == "pq-bf16-x1" else 0)                      # DIGAT_PQ_X1: ... and computed with one bf16 product
+                | (_lib.PARAMS_GEMM_F16X3 if self.resolved_projection_mode() == "fp16x3" else 0))
 
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention

@@ -212,8 +212,7 @@ class MSA(NewsEncoder):
               self.multiheadSelfattention.W_K.weight, self.multiheadSelfattention.W_V.weight,
               self.multiheadSelfattention.W_V.bias, self.attention.affine1.weight, self.attention.affine1.bias,
               self.attention.affine2.weight]
-        from . import _lib as _l
-        key = tuple((w.data_ptr(), w._version) for w in ws) + (_l.lib().digat_get_gemm_format(),)   # split images are per format
+        key = tuple((w.data_ptr(), w._version) for w in ws)
         cached = getattr(self, "_hip_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -230,7 +229,8 @@ class MSA(NewsEncoder):
             _lib.check(L.digat_split_msa_weights(keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), dm, hd,
                                                  qkv.data_ptr(), _lib.stream_ptr()), "digat_split_msa_weights")
             a1 = torch.empty(L.digat_split_weights_bytes(att, hd), dtype=torch.uint8, device=dev)
-            _lib.check(L.digat_split_weights(keep[6].data_ptr(), att, hd, a1.data_ptr(), _lib.stream_ptr()), "digat_split_weights")
+            # the MSA encoder's operand format is bf16x6 (no range limit: word embeddings are whatever the vocabulary file holds)
+            _lib.check(L.digat_split_weights(keep[6].data_ptr(), att, hd, a1.data_ptr(), _lib.GEMM_BF16X6, _lib.stream_ptr()), "digat_split_weights")
             P.qkv_wsplit, P.a1_wsplit = qkv.data_ptr(), a1.data_ptr()
             keep += [qkv, a1]
         self._hip_cache = (key, (P, keep))

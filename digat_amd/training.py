@@ -57,20 +57,11 @@ def _wsplit(n_out, k_in, dev):
     return _lib.workspace(nb, dev, "wsplit")     # rewritten by every call (weights change each step); stream-ordered reuse
 
 
-def _bf16x6(fn, *args):
-    """Run one library call under the bf16x6 operand format (the training path's: gradients have no lower bound, and the
-    two-piece fp16 format of inference underflows on them; include/digat_hip.h digat_set_gemm_format)."""
-    prev = L().digat_set_gemm_format(0)
-    try:
-        return fn(*args)
-    finally:
-        L().digat_set_gemm_format(prev)
-
-
 def _linear_fwd(x_ptr, ld, W, b_ptr, y_ptr, M, N, K, dev, what):
     """y[M,N] = x[M,K] W[N,K]^T (+ b)"""
     if _x3_ok(M, N, K) and ld % 4 == 0:
-        _lib.check(_bf16x6(L().digat_linear_f32x3, x_ptr, ld, W.data_ptr(), b_ptr, y_ptr, N, M, N, K, _wsplit(N, K, dev).data_ptr(), S()), what)
+        # the training path's operand format is bf16x6: gradients have no lower bound, fp16 pieces of 1e-6 are subnormal or zero
+        _lib.check(L().digat_linear_f32x3(x_ptr, ld, W.data_ptr(), b_ptr, y_ptr, N, M, N, K, _wsplit(N, K, dev).data_ptr(), _lib.GEMM_BF16X6, S()), what)
     else:
         _lib.check(L().digat_linear_f32(x_ptr, ld, W.data_ptr(), b_ptr, y_ptr, N, M, N, K, S()), what)
 

@@ -47,6 +47,7 @@ class DeviceCorpus:
     weights_key: Optional[tuple] = None                      # the weight version the five caches above were computed from
     title_text: Optional[torch.Tensor] = None                # [news_num, Lw] int32 token ids (MIND_corpus.py: news_title_text)
     title_mask: Optional[torch.Tensor] = None                # [news_num, Lw] bool                       (news_title_mask)
+    news_key: Optional[tuple] = None                         # the news-encoder weight version news_embedding was computed from
 
     @classmethod
     def from_numpy(cls, corpus, device) -> "DeviceCorpus":
@@ -192,12 +193,15 @@ class GroupedBatchPipeline:
 
     The gathers of a batch are ~10 small kernels (60 us) that would otherwise sit between two encoder calls on the
     same stream.  ``batches`` lists the (start, end) row ranges in the order they will be taken.  The group structure
-    of every batch (unique impressions, row -> group index) is computed once on the host and uploaded once; two sets
-    of static buffers (user side sized for batch_size // 4 groups, the most the grouped entry takes) alternate, and
-    events order gather -> score -> gather on each set."""
+    of every batch (unique impressions, row -> group index) is computed once on the host and uploaded once; ``nsets`` sets
+    of static buffers (user side sized for batch_size // 4 groups, the most the grouped entry takes) take turns, and
+    events order gather -> score -> gather on each set.  A set is refilled only once the batch that last used it has been
+    scored, so at most ``nsets`` batches are in flight: a driver that alternates over n streams wants nsets = n
+    (``score_rows`` passes its lane count; with two sets a third lane only overlapped its prologue)."""
 
-    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray):
+    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray, nsets: int = 2):
         self.dc, self.batches = dc, list(batches)
+        self.nsets = nsets = max(2, int(nsets))
         dev = dc.news_embedding.device
         self.dev = dev
         B = max(e - s for s, e in self.batches)
@@ -218,7 +222,7 @@ class GroupedBatchPipeline:
                         c_n0=torch.empty((B, d), dtype=torch.float32, device=dev),
                         hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None else None),
                         hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None))
-        self.sets = [bufs(), bufs()]
+        self.sets = [bufs() for _ in range(nsets)]
         uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
         for s, e in self.batches:
             imp_b = row_impression_host[s:e]
@@ -231,16 +235,16 @@ class GroupedBatchPipeline:
         self.row_group_all = torch.from_numpy(np.concatenate(rg_parts)).to(dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))       # the corpus tables and the index arrays above
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.done = [None, None]
-        self.meta = [None, None]
+        self.ready = [torch.cuda.Event() for _ in range(nsets)]
+        self.done = [None] * nsets
+        self.meta = [None] * nsets
         self._gather(0)
 
     def _gather(self, k):
         if k >= len(self.batches):
             return
         s, e = self.batches[k]
-        par = k & 1
+        par = k % self.nsets
         G, n = self.uo[k + 1] - self.uo[k], e - s
         if 4 * G > n:                             # too few rows per group for the grouped entry: per-row path
             self.meta[par] = (k, None)
@@ -287,7 +291,7 @@ class GroupedBatchPipeline:
 
     def take(self, k):
         """The 9 inputs of ``Model.inference_grouped`` for batch k, or None (use ``gather_batch`` + ``inference``)."""
-        par = k & 1
+        par = k % self.nsets
         assert self.meta[par] is not None and self.meta[par][0] == k, "batches must be taken in order"
         info = self.meta[par][1]
         if info is None:
@@ -309,8 +313,17 @@ class GroupedBatchPipeline:
         """Call once batch k's kernels are enqueued: the other buffer set may then be refilled for batch k+1."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
-        self.done[k & 1] = ev
+        self.done[k % self.nsets] = ev
         self._gather(k + 1)
+
+    def drain(self):
+        """Make the current stream wait for every batch scored so far and for the gather stream: after this the pipeline (and
+        its buffers, which the caching allocator may hand to someone else) can be dropped."""
+        cur = torch.cuda.current_stream(self.dev)
+        for ev in self.done:
+            if ev is not None:
+                cur.wait_event(ev)
+        cur.wait_stream(self.stream)
 
 
 _batch_streams = {}
@@ -345,7 +358,7 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     batches = [(s, min(s + batch_size, end)) for s in range(start, end, batch_size)]
     lanes = batch_streams(dev, max(1, streams))
     with torch.no_grad():
-        pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy()) if grouped and batches else None
+        pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes)) if grouped and batches else None
         # the parameter block (split weights, folded queries) is (re)built on the first lane BEFORE the other lanes are
         # ordered after it: a rebuild inside the loop would run on one lane while the next batch reads it on the other
         enc = getattr(model, "graph_encoder", None)
@@ -365,6 +378,9 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
                     pipe.scored(k)
     for extra in lanes[1:]:
         lanes[0].wait_stream(extra)
+    if pipe is not None:
+        with torch.cuda.stream(lanes[0]):
+            pipe.drain()                  # its buffers go back to the allocator when this function returns
     return scores
 
 
@@ -392,12 +408,36 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
     ``score_fn(model, dc, start, end, batch_size)`` replaces the scorer (tests)."""
     if hasattr(model, "eval"):
         model.eval()
+    ne = getattr(model, "news_encoder", None)
+    if score_fn is None and dc.title_text is not None and ne is not None and not hasattr(ne, "table"):
+        # a text news encoder (MSA): util.py:24-33 re-encodes every news at the start of each dev / test run — here whenever the
+        # encoder's weights have moved on since news_embedding was computed (training epochs), not otherwise
+        nk = tuple((p.data_ptr(), p._version) for p in ne.parameters())
+        if dc.news_key != nk:
+            dc.news_embedding = cache_news_representations(ne, dc.title_text, dc.title_mask, max(batch_size, 4096))
+            dc.news_key = nk               # a new tensor: weights_key below changes and the per-news caches follow
+    if score_fn is None and hasattr(model.graph_encoder, "range_overflowed"):
+        model.graph_encoder.range_overflowed()                      # clear what earlier calls may have left in the flag
     if score_fn is None and (dc.c_n0 is None or dc.weights_key != weights_key(model.graph_encoder, dc)):
         prepare_news_side(model.graph_encoder, dc, batch_size)      # first use, or the weights moved on since (an optimizer
                                                                     # step, load_state_dict): the per-news caches are stale
     row_imp = dc.row_impression.cpu().numpy()
     start, end = shard_rows(row_imp, world_size, rank)
+    enc = getattr(model, "graph_encoder", None)
+    watch_range = score_fn is None and hasattr(enc, "range_overflowed")
     local = (score_fn or score_rows)(model, dc, start, end, batch_size)
+    if watch_range and enc.range_overflowed():
+        # an fp16x3 GEMM met an activation at or beyond the format's range (|x| >= 4094: node features of a deep layer, say):
+        # its results are degraded or inf.  Under "auto" the run is redone in the range-free bf16x6 format (and stays there);
+        # an explicit "fp16x3" is the caller's word against the data's — refuse to return such scores.
+        if enc.projection_mode != "auto":
+            from ._lib import DigatHipError
+            raise DigatHipError("projection_mode='fp16x3': an activation left the format's range (|x| >= 4094); use 'bf16x6' or 'auto'")
+        import warnings
+        warnings.warn("digat_amd: fp16x3 projections met activations beyond the format's range; re-scoring in bf16x6")
+        enc.range_fallback = True
+        prepare_news_side(enc, dc, batch_size)
+        local = score_rows(model, dc, start, end, batch_size)
     if world_size > 1:
         counts = [shard_rows(row_imp, world_size, r) for r in range(world_size)]
         scores = all_gather_scores(local, [e - s for s, e in counts], group)

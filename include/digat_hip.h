@@ -55,14 +55,16 @@ const char* digat_error_string(int code);
 int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
                      int M, int N, int K, void* stream);
 
-/* The same product on the bf16 matrix cores: every fp32 operand is split exactly into three bf16
- * pieces and the six significant partial products are summed in the fp32 accumulator.  `wsplit`
- * (digat_split_weights_bytes(N, K) bytes) receives the split weights.  M >= 2048, N % 80 == 0, K % 8 == 0. */
+/* The same product on the bf16 / fp16 matrix cores: every fp32 operand is split exactly into three bf16
+ * pieces and the six significant partial products are summed in the fp32 accumulator (format DIGAT_GEMM_BF16X6), or into
+ * two scaled fp16 pieces with three products (DIGAT_GEMM_F16X3; range and accuracy: see the enum below).  `wsplit`
+ * (digat_split_weights_bytes(N, K) bytes, enough for either format) receives the split weights as ready-made LDS images
+ * in the format the caller names; the image remembers it.  M >= 2048, N % 80 == 0, K % 8 == 0. */
 size_t digat_split_weights_bytes(int rows, int K);
-int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, void* stream);
-int digat_split_weights(const float* W, int N, int K, void* wsplit, void* stream);    /* one [N,K] matrix */
+int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, int format, void* stream);
+int digat_split_weights(const float* W, int N, int K, void* wsplit, int format, void* stream);    /* one [N,K] matrix */
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
-                       int M, int N, int K, void* wsplit, void* stream);
+                       int M, int N, int K, void* wsplit, int format, void* stream);
 
 /* ---- a1 / a2: DIGAT.compute_news_graph_embeddings / compute_user_graph_embeddings -------------
  * graphEncoders.py:143-154 / :163-174 (Eq. 8).  X [B,n,d], A [B,n,n] bytes, ctx [B,d] (the OTHER
@@ -144,6 +146,9 @@ enum { DIGAT_NEWS_XATTN_SPARSE = 8 };
  * (README.md:62-66).  Ranking metrics move by < 1e-4 (tests/test_hip_lowprec.py); element-wise the contexts move by ~1e-4.
  * Bit 5: the P and Q segments with the leading bf16 product alone (2^-8 per product) instead of the number bit 2 selects. */
 enum { DIGAT_PQ_BF16 = 16, DIGAT_PQ_X1 = 32 };
+/* digat_params.flags bit 6: every wsplit image of this parameter block (layers' [W|ffn1|ffn2], featureAffine) was split with
+ * format DIGAT_GEMM_F16X3 (two scaled fp16 pieces, three products); clear = DIGAT_GEMM_BF16X6.  See digat_split_proj_weights. */
+enum { DIGAT_PARAMS_GEMM_F16X3 = 64 };
 
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */
@@ -178,7 +183,10 @@ typedef struct digat_params {
     const float *cand_fold_W, *cand_fold_b;
     const float *user_news_fold_W, *user_news_fold_b;
     const float *userAtt_fold_W, *userAtt_fold_b;
-    const void  *featureAffine_wsplit;   /* optional: featureAffine.weight split by digat_split_weights (bf16x6) */
+    const void  *featureAffine_wsplit;   /* optional: featureAffine.weight split by digat_split_weights (same format as the layers') */
+    uint32_t    *range_flag;             /* optional, DIGAT_PARAMS_GEMM_F16X3 only: one device word the fp16x3 GEMMs OR 1 into when an
+                                            activation is at or beyond the format's range (|x| >= 4094, inf or NaN): the caller zeroes it
+                                            before a scoring run and reads it after (digat_amd/util.py re-scores in bf16x6 when set) */
 } digat_params;
 
 /* (K x).(Q c + bQ) = x.(Wf c + bf): fold one ScaledDotProductAttention / user_news pair.
@@ -323,18 +331,23 @@ int digat_sum_nodes(const float* dP, float* dr, int B, int n, int d, void* strea
  * (and their weight gradients) and every reduction stay fp32.  Returns the previous setting. */
 int digat_set_train_precision(int bf16);
 
-/* The operand format of the >= 2048-row matrix-core GEMMs (node projections, featureAffine, the MSA encoder's, the training
- * path's): 0 (default) = every fp32 value as three bf16 pieces, six products — as accurate as an fp32 fma chain; 1 ("fp16x3") =
- * two fp16 pieces (22-23 significant bits), three products on v_mfma_f32_16x16x32_f16: 0.7x the time.  The weights are scaled by
- * 2^10 and the activations by 2^4 on their way in (exact; undone in the epilogue) so that the low pieces of ordinary values are
- * normal fp16 numbers: against fp64 its mean and largest errors are at or below an fp32 fma chain's (tests/test_hip_lowprec.py)
- * for |w| < 63 and 0.01 < |x| < 4094; beyond the upper bounds the result is inf, far below the lower one the pieces are
- * subnormal (an absolute floor of 2^-24 per term).  Process-wide; a split image (digat_split_*) must be used under the setting it was made under.
- * Returns the previous setting.  Initial value: env DIGAT_GEMM_F16X3.  The training entries (digat_*_fwd_train, digat_*_bwd,
- * digat_linear_bwd_input_x3, digat_xattn_project_x3) always use format 0: gradients have no lower bound (1e-6 and below is
- * ordinary) and fp16 pieces of such values are subnormal or zero; bf16 pieces keep fp32's exponent range. */
-int digat_set_gemm_format(int format);
-int digat_get_gemm_format(void);
+/* The operand format of the >= 2048-row matrix-core GEMMs (node projections, featureAffine): DIGAT_GEMM_BF16X6 = every fp32
+ * value as three bf16 pieces, six products — as accurate as an fp32 fma chain, no range limit; DIGAT_GEMM_F16X3 = two fp16
+ * pieces (22-23 significant bits), three products on v_mfma_f32_16x16x32_f16: 0.7x the time.  The weights are scaled by 2^10 and
+ * the activations by 2^4 on their way in (exact; undone in the epilogue) so that the low pieces of ordinary values are normal
+ * fp16 numbers: against fp64 its mean and largest errors are at or below an fp32 fma chain's (tests/test_hip_lowprec.py) for
+ * |w| < 63 and 1e-4 < |x| < 4094; far below the lower bound the pieces are subnormal (an absolute floor of 2^-24 per term);
+ * at the upper bound the high piece saturates (precision degrades to ~2^-15, then inf) — the kernel reports that through
+ * digat_params.range_flag.
+ * There is NO process-wide setting: the format is a property of a split image.  It is chosen by whoever splits the weights
+ * (the `format` argument of digat_split_*), the encoder entry points are told through digat_params.flags & DIGAT_GEMM_F16X3
+ * (every wsplit image of one digat_params has the same format), and the library remembers the format of every image it has
+ * split: a launch that names the other format returns DIGAT_ERR_ARG instead of misreading the image.  The training entries
+ * (digat_*_fwd_train, digat_*_bwd, digat_linear_bwd_input_x3, digat_xattn_project_x3) and the MSA encoder split their weights in
+ * DIGAT_GEMM_BF16X6: gradients have no lower bound (1e-6 and below is ordinary) and fp16 pieces of such values are subnormal or
+ * zero; bf16 pieces keep fp32's exponent range.  Two host threads on two streams may therefore run an fp16x3 evaluation and a
+ * training step at the same time. */
+enum { DIGAT_GEMM_BF16X6 = 0, DIGAT_GEMM_F16X3 = 1 };
 
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
  * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one

@@ -44,11 +44,12 @@ def test_workspace_queries():
 
 
 def test_struct_layout_matches_header():
-    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 7 pointers + 6 folded-query pointers + 1 split-weight pointer."""
+    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 8 pointers + 6 folded-query pointers + 1 split-weight pointer
+    + the range-flag pointer."""
     import ctypes
     from digat_amd import _lib
     assert ctypes.sizeof(_lib.LayerParams) == 8 * 8
-    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 8 * 8 + 7 * 8
+    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 8 * 8 + 8 * 8
 
 
 def test_module_mirrors_reference_parameter_names():
@@ -77,6 +78,18 @@ def test_no_cpu_fallback():
         enc(*(torch.from_numpy(np.ascontiguousarray(b[k])) for k in
               ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
                "user_category_mask", "user_category_indices")))
+
+
+def test_no_process_wide_operand_format():
+    """The matrix-core operand format travels with the split image / digat_params.flags: the library has no setter for it
+    and no mutable global behind one."""
+    from digat_amd import _lib
+    L = _lib.lib()
+    assert not hasattr(L, "digat_set_gemm_format") and not hasattr(L, "digat_get_gemm_format")
+    csrc = os.path.join(REPO, "digat_amd", "csrc")
+    for f in os.listdir(csrc):
+        text = open(os.path.join(csrc, f)).read()
+        assert "g_gemm_format" not in text and "GemmFormatScope" not in text, f
 
 
 def test_product_package_does_not_import_the_oracle():

@@ -62,6 +62,21 @@ def test_bench_two_ranks_sum_their_rows():
     assert len(line["per_rank_impressions_per_s"]) == 2 and all(v > 0 for v in line["per_rank_impressions_per_s"])
 
 
+def test_bench_two_gpus_starts_its_own_launcher():
+    """``python bench.py --gpus 2`` with no outer launcher (how a driver may start the scaling runs): the parent starts
+    torch.distributed.run as a child before touching the GPU and relays its JSON line and exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DIGAT_BENCH_TEST_SHARED_GPU="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "600", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["ranks_in_process_group"] == 2
+    assert line["config"]["backend"] == "gloo"            # the one-GPU test hook; "nccl" (RCCL) on a multi-GPU node
+    assert line["auc_match"]["max_abs_metric_diff"] <= 1e-4
+
+
 def test_bench_train_mode_two_ranks_ddp():
     """--mode train under torch.distributed.run: DistributedDataParallel around Model.forward / the HIP backward."""
     env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")

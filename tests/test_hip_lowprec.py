@@ -105,17 +105,17 @@ def test_bf16_eq8_operands_on_the_small_devsets(name):
 
 
 def test_fp16x3_projections_keep_scores_and_metrics():
-    """projection_mode "fp16x3" (digat_set_gemm_format(1)): every matrix-core operand as two fp16 pieces, three products.  On the
+    """projection_mode "fp16x3" (split images of format DIGAT_GEMM_F16X3): every matrix-core operand as two fp16 pieces, three products.  On the
     reference-pinned 2 000-impression dev set the scores stay within 1e-4 relative of the reference's and the metrics within
     1e-5 — a tenth of the reference's criterion — while the projections take 0.7x the time."""
     from digat_amd import _lib, util
     fx, corpus, model, dc = build_2k()
     model.graph_encoder.projection_mode = "bf16x6"
     base, base_metrics = util.compute_scores(model, dc, 1024, labels=corpus.row_label)
-    assert _lib.lib().digat_get_gemm_format() == 0
+    assert not model.graph_encoder._params().flags & _lib.PARAMS_GEMM_F16X3
     model.graph_encoder.projection_mode = "fp16x3"
     scores, metrics = util.compute_scores(model, dc, 1024, labels=corpus.row_label)
-    assert _lib.lib().digat_get_gemm_format() == 1
+    assert model.graph_encoder._params().flags & _lib.PARAMS_GEMM_F16X3
     assert not np.array_equal(scores, base), "the fp16x3 path did not run"
     rel = report(scores, fx, "fp16x3")
     drift = np.abs(np.array(metrics) - fx["metrics"])
@@ -124,10 +124,14 @@ def test_fp16x3_projections_keep_scores_and_metrics():
     assert rel.max() < 1e-4 and drift.max() <= 1e-5, (rel.max(), drift)
 
 
-@pytest.mark.parametrize("M,N,K,scale", [(4100, 400, 400, 1.0), (34304, 1200, 400, 1.0), (4100, 400, 400, 100.0), (2500, 160, 72, 0.01)])
+@pytest.mark.parametrize("M,N,K,scale", [(4100, 400, 400, 1.0), (34304, 1200, 400, 1.0), (4100, 400, 400, 100.0), (2500, 160, 72, 0.01),
+                                         (4100, 400, 400, 1e-3), (4100, 400, 400, 1e-4)])
 def test_fp16x3_linear_error_against_fp64(M, N, K, scale):
     """The two-piece fp16 product against an fp64 product, next to the fp32-MFMA kernel (an exact k-ordered fp32 fma chain) on the
-    same data: mean and max error at most 1.1x the chain's (measured 0.75x / 0.7x at unit scale, 1.0x for |x| ~ 0.01)."""
+    same data: mean and max error at most 1.1x the chain's (measured 0.75x / 0.7x at unit scale, 1.0x for |x| ~ 0.01).  Below
+    |x| ~ 1e-3 the low pieces are fp16 subnormals (quantum 2^-24 after the format's 2^4 scaling = 3.7e-9 of x): the error then
+    has an ABSOLUTE floor — K terms of 2^-29 |w| each — which is reported and bounded, not hidden (the chain's own error shrinks
+    with x; the format's does not)."""
     from digat_amd import _lib
     rng = np.random.default_rng(M + N + K)
     x = (rng.standard_normal((M, K)) * scale).astype(np.float32)
@@ -139,12 +143,8 @@ def test_fp16x3_linear_error_against_fp64(M, N, K, scale):
     y16 = torch.full((M, N), float("nan"), device=DEV)
     y32 = torch.full((M, N), float("nan"), device=DEV)
     ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=DEV)
-    prev = L.digat_set_gemm_format(1)
-    try:
-        _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y16.data_ptr(), N, M, N, K, ws.data_ptr(),
-                                        _lib.stream_ptr()), "digat_linear_f32x3")
-    finally:
-        L.digat_set_gemm_format(prev)
+    _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y16.data_ptr(), N, M, N, K, ws.data_ptr(),
+                                    _lib.GEMM_F16X3, _lib.stream_ptr()), "digat_linear_f32x3")
     _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K, _lib.stream_ptr()),
                "digat_linear_f32")
     torch.cuda.synchronize()
@@ -152,4 +152,12 @@ def test_fp16x3_linear_error_against_fp64(M, N, K, scale):
     e32 = np.abs(y32.cpu().numpy().astype(np.float64) - want)
     print(f"\n[fp16x3 {M}x{N}x{K} x{scale}] mean {e16.mean():.3e} (fp32 chain {e32.mean():.3e}), max {e16.max():.3e} ({e32.max():.3e})")
     assert np.isfinite(e16).all()
-    assert e16.mean() <= 1.1 * e32.mean() + 1e-9 and e16.max() <= 1.1 * e32.max() + 1e-8
+    if scale >= 0.01:
+        assert e16.mean() <= 1.1 * e32.mean() + 1e-9 and e16.max() <= 1.1 * e32.max() + 1e-8
+    else:
+        # subnormal low pieces: an absolute floor of ~sqrt(K) * 2^-29 * |w| per output (|w| ~ 1 / sqrt(K): ~2e-9), i.e. relative
+        # to outputs of size `scale` 2e-6 at 1e-3 and 2e-5 at 1e-4 — fp32-grade no longer, still far inside the 1e-4 the path
+        # is held to; "auto" therefore wants features of ordinary size (news representations: 0.1 .. 10)
+        floor = np.sqrt(K) * 2.0 ** -29 / np.sqrt(K) * 4
+        print(f"    relative to the outputs' scale {scale}: mean {e16.mean() / scale:.2e}, max {e16.max() / scale:.2e}; floor bound {floor:.2e}")
+        assert e16.mean() <= e32.mean() + floor and e16.max() <= e32.max() + 8 * floor

@@ -113,7 +113,7 @@ def test_linear_bf16x6_is_fp32_grade(M, N, K):
     y32 = torch.full((M, N), float("nan"), device=_dev())
     ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=_dev())
     _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y6.data_ptr(), N, M, N, K,
-                                    ws.data_ptr(), _lib.stream_ptr()), "digat_linear_f32x3")
+                                    ws.data_ptr(), _lib.GEMM_BF16X6, _lib.stream_ptr()), "digat_linear_f32x3")
     _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K,
                                   _lib.stream_ptr()), "digat_linear_f32")
     torch.cuda.synchronize()
@@ -133,7 +133,10 @@ def test_projection_modes_agree():
             "user_category_mask", "user_category_indices")
     enc = make_encoder(state, N, H, C, d, L)
     outs = {}
-    assert enc.projection_mode == "auto" and enc.resolved_projection_mode() == "fp16x3"      # Xavier-sized weights: far below 32
+    # "auto" without a driver that watches the range flag (direct forward / inference calls): the range-free format
+    assert enc.projection_mode == "auto" and enc.resolved_projection_mode() == "bf16x6"
+    enc.corpus_activation_max = 2.0                # what util.prepare_news_side reports: the driver is there and checks the flag
+    assert enc.resolved_projection_mode() == "fp16x3"      # Xavier-sized weights: far below 32
     for mode in ("fp32", "bf16x6", "fp16x3"):
         enc.projection_mode = mode
         with torch.no_grad():
@@ -150,6 +153,15 @@ def test_projection_modes_agree():
         enc.featureAffine.weight[0, 0] = 0.01
     assert enc.resolved_projection_mode() == "fp16x3"
     enc.corpus_activation_max = 1000.0             # ... and so do news representations beyond 256 (util.prepare_news_side reports them)
+    assert enc.resolved_projection_mode() == "bf16x6"
+    enc.corpus_activation_max = 2.0
+    with torch.no_grad():
+        enc.topic_node_embedding[0, 0] = 300.0     # ... and topic nodes beyond 256
+    assert enc.resolved_projection_mode() == "bf16x6"
+    with torch.no_grad():
+        enc.topic_node_embedding[0, 0] = 0.01
+    assert enc.resolved_projection_mode() == "fp16x3"
+    enc.range_fallback = True                      # ... and a run whose activations left the range (util.compute_scores)
     assert enc.resolved_projection_mode() == "bf16x6"
 
 

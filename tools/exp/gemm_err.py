@@ -12,7 +12,7 @@ for (M, N, K, xs) in [(4100, 400, 400, 1.0), (34304, 1200, 400, 1.0), (4100, 400
     xd, wd, bd = (torch.from_numpy(a).to(dev) for a in (x, w, b))
     y6 = torch.empty((M, N), device=dev); y32 = torch.empty((M, N), device=dev)
     ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=dev)
-    _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y6.data_ptr(), N, M, N, K, ws.data_ptr(), _lib.stream_ptr()), "x3")
+    _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y6.data_ptr(), N, M, N, K, ws.data_ptr(), int(os.environ.get('FMT', '0')), _lib.stream_ptr()), "x3")
     _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K, _lib.stream_ptr()), "f32")
     yt = torch.addmm(bd, xd, wd.t())
     torch.cuda.synchronize()

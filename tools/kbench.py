@@ -113,7 +113,7 @@ def bench_linear(M=68608, N=400, K=400):
 
         def run6():
             _lib.check(L.digat_linear_f32x3(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y6.data_ptr(), N, M, N, K,
-                                            ws.data_ptr(), _lib.stream_ptr()), "linear x3")
+                                            ws.data_ptr(), int(os.environ.get("KBENCH_GEMM_FORMAT", "0")), _lib.stream_ptr()), "linear x3")
         m6, b6 = timeit(run6)
         print(f"   bf16x6 (incl. weight split): median {m6*1e3:.1f} us best {b6*1e3:.1f} us  {fl/m6/1e9:.1f} fp32-equivalent TFLOP/s"
               f"  max|diff vs fp32 kernel| {float((y6 - y).abs().max()):.2e}")
