@@ -442,6 +442,8 @@ struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
 static int g_sparse_per_node = getenv("DIGAT_SPARSE_PER_NODE") ? atoi(getenv("DIGAT_SPARSE_PER_NODE")) : 12;
 static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
+// layer 0 of the user graph on the live nodes only (A/B switch for measurements; DIGAT_L0_LIVE=0: every node at layer 0)
+static int g_l0_live_on = getenv("DIGAT_L0_LIVE") ? atoi(getenv("DIGAT_L0_LIVE")) : 1;
 // 0 (default): the wave-per-centre sparse kernel; 1: the LDS-staged kernels of digat_staged.inc (compulsory HBM traffic, measured
 // slower in round 2: DESIGN.md section 4)
 static int g_staged_on = getenv("DIGAT_XATTN_STAGED") ? atoi(getenv("DIGAT_XATTN_STAGED")) : 0;
@@ -500,8 +502,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         return launch_gemm(g, sq);
     };
-    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr) -> int {
-        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup);
+    // `live` (layers' outputs): the rows of dead nodes were never written — the topic pooling takes them as zero
+    auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr,
+                             const uint8_t* live = nullptr) -> int {
+        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup, live, U);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
@@ -675,7 +679,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rc = group_project(side->s);
         if (rc) return rc;
     }
-    if (group_early || plan_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO)) {
+    if (group_early || plan_early || live_early) {
         if (hipEventRecord(side->early, side->s) != hipSuccess) return DIGAT_ERR_LAUNCH;
     }
     if (news_early && !news_hpq0) {      // news_hpq0: the caller kept layer 0's news projections per news (digat_news_project0)
@@ -709,9 +713,15 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = make_plan(st);
             if (rc) return rc;
         }
-        if (i == 0 && side && (group_early || plan_early || (live_early && sparse_mode == DIGAT_XATTN_AUTO))) {
+        if (i == 0 && side && (group_early || plan_early || live_early)) {
             if (hipStreamWaitEvent(st, side->early, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
         }
+        // The live lists are in force from layer 0 on: a dead node (a history padding slot, the topic node of an unread category:
+        // only its self loop, pooled with weight 0) is never projected, scored or written, in ANY layer.  Its rows of the two
+        // node buffers therefore hold whatever the workspace held; the one reader that walks all history rows — the topic
+        // pooling — takes them as zero through the flags (a select: no bits of such a row can reach a result;
+        // test_uninitialised_workspace_cannot_reach_the_outputs fills the scratch with NaN patterns).
+        if (i == 0 && want_live) publish_live_rows();
         if (i == 0 && row_group) {
             const size_t ndg = (size_t)G * U * d;
             const size_t nd = (size_t)B * U * d;
@@ -726,12 +736,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = DIGAT_OK;
             if (sparse_mode != DIGAT_XATTN_DENSE && d / 4 <= 256) {
                 // P' = K1 (the groups' P0) + K3 (this layer's r_user) is formed inside the kernel: nothing is expanded
-                const SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, nullptr,
+                // live centres only (the list of find_live_rows), P / Q / h / X read through the group index.  The staged kernels
+                // (opt-in) keep the older arrangement: every centre computed, and the dead rows of the other buffer filled with X_i
+                const bool l0_live = want_live && live_flags && !use_staged && g_l0_live_on;
+                const SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, l0_live ? live_flags : nullptr,
                                     sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, xu0_grouped ? 1 : 0,
-                                    // Xu[0] was never written: the rows of dead nodes, which layer 1 will not write there and
-                                    // the topic pooling after it reads (weight 0, but 0 * NaN = NaN), get X_i now
-                                    (xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
-                                    nullptr, nullptr, G, nullptr, 0, 0};
+                                    (!l0_live && xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
+                                    l0_live ? rowidx : nullptr, l0_live ? nrows_dev : nullptr, G, nullptr, 0, 0};
                 rc = use_staged ? launch_staged(sg, plan, 0, 0, st) : launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
@@ -750,9 +761,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                            skip_if);
             }
         } else {
-            // layer 0 computes every row (the buffers then hold finite values everywhere); later layers only the live ones
+            // every layer projects, scores and writes the live nodes only (layer 0 too: see publish_live_rows above)
+            const bool lv_on = i > 0 || (g_l0_live_on && !use_staged);
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
-                            i > 0 ? rowidx : nullptr, i > 0 ? nrows_dev : nullptr, i > 0 ? live_flags : nullptr, sparse_mode,
+                            lv_on ? rowidx : nullptr, lv_on ? nrows_dev : nullptr, lv_on ? live_flags : nullptr, sparse_mode,
                             sparse_flag, pq_x3, use_staged ? &plan : nullptr, i,
                             i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) : 0,
                             // after the last layer only the history rows are read (the user context's topic pooling, :124):
@@ -762,7 +774,6 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
-        if (i == 0 && want_live) publish_live_rows();       // consumers: the user context of this layer, layers >= 1
         rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
         if (rc) return rc;
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
@@ -794,7 +805,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         // The user context of this layer feeds the next NEWS update and the result, not the next user-graph update: it runs
         // on the side stream once the caller's stream has written the user nodes, under the next layer's projection GEMM.
         if (side && hipStreamWaitEvent(sn, side->fork, 0) != hipSuccess) return DIGAT_ERR_LAUNCH;
-        rc = user_ctx_tail(Xu[un], c_u, sn);       // c_u += ... (:197)
+        rc = user_ctx_tail(Xu[un], c_u, sn, nullptr, live_flags);       // c_u += ... (:197)
         if (rc) return rc;
     }
     if (side && L > 0) {

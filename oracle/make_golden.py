@@ -374,6 +374,45 @@ def fixture_devset_2k(ge, ev):
                                    + float(corpus.row_candidate.astype(np.float64).sum())))
 
 
+def fixture_devset_trained_2k(ge, ev):
+    """(iv-c) the dev split of the PLANTED-SIGNAL corpus scored by the reference with TRAINED weights.  Every other dev fixture
+    uses Xavier weights on random clicks (AUC 0.5, logits of rms ~600: rank equality on widely spread scores).  Here the clicks
+    follow sub-topic preferences (synthetic.PLANTED_SPEC), the graph encoder was trained on impressions [2000, 6000) of that
+    corpus by tools/train_planted.py on the GPU box (digat_amd's own trainer: Adam 3e-4, 4 epochs, dropout 0.2) and its state
+    dict travels as data (tests/golden/trained_planted_state.npz); the reference scores the held-out impressions [0, 2000):
+    AUC ~0.64, logits of rms ~10, near-ties between candidates as a trained model has them."""
+    full = synthetic.make_corpus(synthetic.SynthSpec(**synthetic.PLANTED_SPEC))
+    corpus = synthetic.slice_impressions(full, 0, synthetic.PLANTED_DEV_IMPRESSIONS)
+    spec = corpus.spec
+    state = {k: v for k, v in np.load(os.path.join(GOLDEN, "trained_planted_state.npz")).items()}
+    L = sum(1 for k in state if k.startswith("user_graph_attention_a."))
+    enc = reference_encoder(ge, spec.news_graph_size, spec.max_history_num, spec.category_num, spec.embedding_dim, L, state)
+    scores, c_n0 = reference_scores(enc, corpus, 128)
+    sub = [[] for _ in range(int(corpus.row_impression[-1]) + 1)]
+    labels = [[] for _ in sub]
+    for i, imp in enumerate(corpus.row_impression.tolist()):
+        sub[imp].append([float(scores[i]), len(sub[imp])])
+        labels[imp].append(int(corpus.row_label[i]))
+    lines, truth = [], []
+    for i, s in enumerate(sub):                                             # util.py:70-80
+        s.sort(key=lambda x: x[0], reverse=True)
+        res = [0] * len(s)
+        for j in range(len(s)):
+            res[s[j][1]] = j + 1
+        lines.append(str(i + 1) + " " + str(res).replace(" ", ""))
+        truth.append(str(i + 1) + " " + str(labels[i]).replace(" ", ""))
+    auc, mrr, n5, n10 = ev.scoring(io.StringIO("\n".join(truth)), io.StringIO("\n".join(lines)))
+    print(f"  devset_trained_2k: rows={corpus.rows} AUC={auc:.6f} MRR={mrr:.6f} nDCG5={n5:.6f} nDCG10={n10:.6f} "
+          f"logits rms {float(np.sqrt((scores.astype(np.float64) ** 2).mean())):.2f}")
+    ranks = np.concatenate([np.array(eval(l.split(" ", 1)[1]), dtype=np.int16) for l in lines])   # our own output lines
+    save("devset_trained_2k.npz", depth=np.array(L), scores=scores.astype(np.float32), ranks=ranks,
+         c_n0_head=c_n0[:64].astype(np.float32), metrics=np.array([auc, mrr, n5, n10], dtype=np.float64),
+         input_checksum=np.float64(float(corpus.news_embedding.astype(np.float64).sum())
+                                   + float(corpus.user_graph.sum()) + float(corpus.news_graph.sum())
+                                   + float(corpus.row_candidate.astype(np.float64).sum()) + float(corpus.row_label.sum())),
+         state_checksum=np.float64(sum(float(np.asarray(v, dtype=np.float64).sum()) for v in state.values())))
+
+
 def fixture_ablations(ge):
     """the five ablation encoders (graphEncoders.py:201-842), eval-mode forward and inference, at the tiny
     shapes (inputs stored) and at the default shapes (inputs and weights regenerate from seeds).  Loading the
@@ -569,7 +608,8 @@ def main():
             "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge),
             "ablation_train": lambda: fixture_ablation_train(ge), "msa": fixture_msa,
             "msa_train": fixture_msa_train,
-            "sag": fixture_sag, "devset_2k": lambda: fixture_devset_2k(ge, ev)}
+            "sag": fixture_sag, "devset_2k": lambda: fixture_devset_2k(ge, ev),
+            "devset_trained_2k": lambda: fixture_devset_trained_2k(ge, ev)}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]        # python oracle/make_golden.py [name ...]
     for name in (only or list(jobs)):
         jobs[name]()
