@@ -490,6 +490,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     float* glob = (float*)((char*)cws + 2 * s2);  // [B,d]; cws holds >= 2*s2 + 2*[B,d] (user-context layout)
     const int* bucket_idx = nullptr;              // live topic buckets (set by find_live_rows during layer 0)
     const int* nbuckets_dev = nullptr;
+    const int* hist_last = nullptr;               // [B]: 1 + the last live history slot of every row (published with the lists)
     int rc;
     // the user-side queries + (optionally) the next user-graph K3, all from c_n
     auto from_c_n = [&](int next_layer, hipStream_t sq) -> int {
@@ -505,7 +506,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     // `live` (layers' outputs): the rows of dead nodes were never written — the topic pooling takes them as zero
     auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr,
                              const uint8_t* live = nullptr) -> int {
-        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup, live, U);
+        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup, live, U, live ? hist_last : nullptr);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
@@ -546,7 +547,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     uint8_t* live_flags = nullptr;
     // launches the list kernels on `sq`; `publish` hands the lists to the code below (the initial user context, issued on
     // the caller's stream at the same time, must not see them: only a join orders the caller's stream after the side stream)
-    const int *pend_rowidx = nullptr, *pend_nrows = nullptr, *pend_bidx = nullptr, *pend_nb = nullptr;
+    const int *pend_rowidx = nullptr, *pend_nrows = nullptr, *pend_bidx = nullptr, *pend_nb = nullptr, *pend_hlast = nullptr;
+
     uint8_t* pend_flags = nullptr;
     auto find_live_rows = [&](hipStream_t sq) -> int {
         int* cnt = live_ws;
@@ -557,11 +559,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         int* idx2 = off2 + align_up((size_t)B + 1, 64);
         int* entries = idx2 + align_up((size_t)B * C1, 64);
         int* flag = entries + align_up((size_t)B, 64);
-        uint8_t* flags1 = (uint8_t*)(flag + 64);
+        int* hlast = flag + 64;
+        uint8_t* flags1 = (uint8_t*)(hlast + align_up((size_t)B, 64));
         uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr);
+                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast);
         DIGAT_CHECK_LAUNCH();
         if (sparse_mode == DIGAT_XATTN_AUTO) {
             hipLaunchKernelGGL(sparse_decide_kernel, dim3(1), dim3(1024), 0, sq, (const int*)entries, B, U, g_sparse_per_node, flag);
@@ -578,7 +581,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         DIGAT_CHECK_LAUNCH();
         hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags2, (const int*)off2, B, C1, idx2);
         DIGAT_CHECK_LAUNCH();
-        pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1;
+        pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1; pend_hlast = hlast;
         return DIGAT_OK;
     };
     // the plan follows the live flags on the same stream (its second list is the live centres)
@@ -590,6 +593,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     };
     auto publish_live_rows = [&]() {
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
+        hist_last = pend_hlast;
     };
     SideStream* side = side_stream(st);
     // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
@@ -828,7 +832,7 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     tot += digat_xattn_workspace_bytes(B, N, d);         // the news graph's own Eq. 8 workspace (side stream)
     // live-node and live-bucket counts, offsets, lists (int) and flags (bytes)
     // + adjacency entries per row and the sparse / dense decision (int)
-    tot += align_up((3 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
+    tot += align_up((4 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
                      + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256), 256);
     tot += plan_bytes(B, U);                             // the staged Eq. 8 kernel's plan of the batch (digat_staged.inc)
     return tot;
