@@ -288,6 +288,15 @@ int digat_split_weights(const float* W, int N, int K, void* wsplit, int format, 
     return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream, 0, format);
 }
 
+#ifdef DIGAT_GEMM_TIMERS
+int digat_debug_gemm_timers(double* out8) {
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_timers), sizeof(h)) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    for (int k = 0; k < 8; ++k) { out8[k] = (double)h[k]; h[k] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timers), h, sizeof(h)) == hipSuccess ? DIGAT_OK : DIGAT_ERR_LAUNCH;
+}
+#endif
+
 // BASELINE configs[4], training half: the >= 2048-row GEMMs of the training path (projections, featureAffine, input
 // gradients) with ONE bf16 product per fp32 product — plain bf16 mixed precision: fp32 master weights and activations, bf16
 // matrix-core operands, fp32 accumulation — instead of the six of the fp32-grade split (the >= 2048-row weight gradients included: gemm_tn_bf16x6_kernel<true>).
