@@ -19,6 +19,23 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+def planted_devset():
+    """(fixture, dev corpus, trained state dict) of tests/golden/devset_trained_2k.npz: the held-out impressions [0, 2000) of the
+    planted-signal corpus, scored by the imported reference with the weights tools/train_planted.py trained on the GPU box
+    (tests/golden/trained_planted_state.npz).  AUC ~0.64, logits of rms ~10: a model that ranks."""
+    from digat_amd import synthetic
+    fx = load_golden("devset_trained_2k.npz")
+    full = synthetic.make_corpus(synthetic.SynthSpec(**synthetic.PLANTED_SPEC))
+    corpus = synthetic.slice_impressions(full, 0, synthetic.PLANTED_DEV_IMPRESSIONS)
+    state = load_golden("trained_planted_state.npz")
+    chk = (float(corpus.news_embedding.astype(np.float64).sum()) + float(corpus.user_graph.sum()) + float(corpus.news_graph.sum())
+           + float(corpus.row_candidate.astype(np.float64).sum()) + float(corpus.row_label.sum()))
+    assert abs(chk - float(fx["input_checksum"])) <= 1e-6 * abs(chk), "synthetic generator drifted from the fixture's"
+    wchk = sum(float(np.asarray(v, dtype=np.float64).sum()) for v in state.values())
+    assert abs(wchk - float(fx["state_checksum"])) <= 1e-9 * max(1.0, abs(wchk)), "trained weights differ from the ones the fixture was minted with"
+    return fx, corpus, state
+
+
 def split_fixture(fx):
     """(inputs, weights, outputs) of a fixture that stores all three."""
     ins = {k[3:]: v for k, v in fx.items() if k.startswith("in_")}

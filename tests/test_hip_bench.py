@@ -22,8 +22,8 @@ def _last_json_line(out):
 
 def test_bench_single_gpu_prints_the_contract_line():
     cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "600", "--news", "2048",
-           "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+           "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2", "--e2e-impressions", "1500"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert REQUIRED <= set(line) and "cpu_baseline" in line
@@ -38,6 +38,14 @@ def test_bench_single_gpu_prints_the_contract_line():
     rx = line["roofline_xattn"]
     assert rx["bound"] == "hbm" and 0 < rx["frac"] < 1
     assert line["setup_ms"] > 0 and line["config"]["news_num"] == 2048
+    # the same criterion on a model that ranks: trained weights on the planted-signal dev split vs the imported reference's scores
+    tr = line["auc_match_trained"]
+    assert tr["rows"] > 70000 and tr["reference"][0] > 0.60 and tr["max_abs_metric_diff"] <= 1e-4 and tr["ranks_equal_fraction"] > 0.999
+    assert line["fp16x3_range_overflow"] is False
+    # the end-to-end dev run (title tokens -> rank file), here on 1 500 impressions
+    e2e = line["e2e"]
+    assert e2e["impressions"] == 1500 and e2e["seconds"] > 0 and e2e["rank_file_bytes"] > 0
+    assert abs(sum(e2e["breakdown_s"].values()) - e2e["seconds"]) < 0.05 * e2e["seconds"] + 0.01
     ex = line["extra_workloads"]
     assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16", "mind-small-default/bf16x6"}
     assert all(v["value"] > 0 for v in ex.values())
@@ -45,6 +53,8 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert ex["mind-small-default/bf16x6"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4
     assert ex["mind-small-default/pq-bf16"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4          # BASELINE configs[4], inference half
     assert ex["mind-small-stress"]["config"]["N"] == 65 and ex["mind-large-default"]["config"]["N"] == 26
+    for k in ("mind-small-stress", "mind-large-default"):        # configs[2] / configs[3]: their own rooflines
+        assert 0 < ex[k]["roofline"]["frac"] < 1 and 0 < ex[k]["roofline_xattn"]["frac"] < 1 and ex[k]["kernel_ms_per_step_single_stream"]
 
 
 def test_bench_two_ranks_sum_their_rows():

@@ -275,6 +275,55 @@ def test_oracle_on_a_slice_of_the_2k_devset():
     assert np.allclose(got, want, rtol=2e-5, atol=1e-4), np.abs(got - want).max()
 
 
+def test_oracle_on_a_slice_of_the_trained_devset():
+    """devset_trained_2k.npz: TRAINED weights (AUC 0.64, logits of rms ~10) on the planted-signal corpus, scored by the reference.
+    The oracle on the first impressions; the fixture's labels are not random: its stored metrics must say the model ranks."""
+    from conftest import planted_devset
+    fx, corpus, state = planted_devset()
+    assert fx["metrics"][0] > 0.60 and 3.0 < float(np.sqrt((fx["scores"].astype(np.float64) ** 2).mean())) < 30.0
+    L = int(fx["depth"])
+    p = O.as_params(state)
+    spec = corpus.spec
+    rows = int(np.searchsorted(corpus.row_impression, 8))            # the first 8 impressions
+    emb = torch.from_numpy(corpus.news_embedding)
+    cand = torch.from_numpy(corpus.row_candidate[:rows].astype(np.int64))
+    ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64)).index_select(0, cand)
+    sa = emb.index_select(0, ids.flatten()).view(rows, -1, spec.embedding_dim)
+    masks = torch.from_numpy(corpus.news_graph_mask).index_select(0, cand)
+    graphs = torch.from_numpy(corpus.news_graph).index_select(0, cand)
+    imp = torch.from_numpy(corpus.row_impression[:rows])
+    hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+    ue = emb.index_select(0, hist.flatten()).view(rows, spec.max_history_num, spec.embedding_dim)
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        got = O.row_logits(p, L, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                           torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                           torch.from_numpy(corpus.user_category_indices).index_select(0, imp), sa, graphs, masks, c_n0).numpy()
+    want = fx["scores"][:rows]
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5), np.abs(got - want).max()
+
+
+def test_planted_signal_corpus_is_rankable_and_the_default_corpus_is_unchanged():
+    """synthetic.SynthSpec(signal=...): a trivial scorer (mean history embedding . candidate embedding) ranks the planted corpus
+    well above chance; with signal = 0 the generator is bit for bit what the older fixtures were minted with."""
+    from digat_amd import evaluate, synthetic
+    spec = synthetic.SynthSpec(news_num=1024, impressions=300, seed=3, signal=2.0, embedding_scale=0.12)
+    c = synthetic.make_corpus(spec)
+    valid = c.history > 0
+    um = (c.news_embedding[c.history] * valid[..., None]).sum(1) / np.maximum(valid.sum(1, keepdims=True), 1)
+    sc = (um[c.row_impression] * c.news_embedding[c.row_candidate]).sum(1)
+    auc = evaluate.scoring(c.row_label, evaluate.impression_ranks(sc, c.row_impression), c.row_impression)[0]
+    assert auc > 0.62, auc
+    sub = synthetic.slice_impressions(c, 100, 200)
+    assert sub.spec.impressions == 100 and sub.row_impression.min() == 0 and sub.row_impression.max() == 99
+    assert sub.rows == int(((c.row_impression >= 100) & (c.row_impression < 200)).sum())
+    fx = load_golden("devset_2k.npz")                            # minted before the signal option existed
+    base = synthetic.make_corpus(synthetic.SynthSpec(news_num=4096, sag_neighbors=3, sag_hops=2, impressions=2000, seed=47))
+    chk = (float(base.news_embedding.astype(np.float64).sum()) + float(base.user_graph.sum()) + float(base.news_graph.sum())
+           + float(base.row_candidate.astype(np.float64).sum()))
+    assert abs(chk - float(fx["input_checksum"])) <= 1e-6 * abs(chk)
+
+
 ABLATION_TRAIN = [(n, "tiny") for n in O.ABLATIONS] + [("wo_interaction", "default")]
 
 
