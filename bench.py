@@ -452,6 +452,8 @@ def rooflines(W, run, args):
             # 3 for P and Q = 4 on average): price the EXECUTED bf16 flops against the dense bf16 peak, and quote the
             # fp32-equivalent rate
             nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-bf16-x1": 8.0 / 3.0, "fp16x3": 3.0}[pmode]
+            if hasattr(enc, "gemm_format") and enc.gemm_format() == 1:          # two fp16 pieces: three products whatever the mode
+                nprod = 3.0
             return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": nprod * rate / 1e12,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": nprod * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": pmc_traffic(kind),

@@ -101,6 +101,11 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_a
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {        // s_waitcnt vmcnt(N) with a compile-time N (0 .. 63)
+    // gfx9 encoding of the s_waitcnt immediate: vmcnt low bits [3:0], expcnt [6:4] = 7, lgkmcnt [11:8] = 15, vmcnt high bits [15:14]
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
 __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;

@@ -130,7 +130,7 @@ class DIGAT(GraphEncoder):
         # the matrix-core operand format ("fp16x3": two fp16 pieces, three products; everything else: three bf16 pieces, six
         # products) is a property of the split images made below and travels in P.flags: nothing process-wide
         pm = self.resolved_projection_mode()
-        fmt = _lib.GEMM_F16X3 if pm == "fp16x3" else _lib.GEMM_BF16X6
+        fmt = self.gemm_format()
         ptrs = tuple(p.data_ptr() for p in self.parameters())
         if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
             # the Eq. 8 variant only selects kernels (P.flags): it never invalidates the split weights or the folded
@@ -202,8 +202,17 @@ class DIGAT(GraphEncoder):
 
     def resolved_projection_mode(self) -> str:
         """``projection_mode`` with "auto" resolved from the weights' range (once per weight version; one host sync)."""
-        if self.projection_mode != "auto":
-            return self.projection_mode
+        return self._auto_base() if self.projection_mode == "auto" else self.projection_mode
+
+    def gemm_format(self) -> int:
+        """The operand format of this encoder's split weight images: fp16x3 when asked for, and under "auto" / "pq-bf16" whenever
+        the range conditions of ``_auto_base`` hold; bf16x6 otherwise."""
+        pm = self.projection_mode
+        if pm == "fp16x3" or (pm in ("auto", "pq-bf16") and self._auto_base() == "fp16x3"):
+            return _lib.GEMM_F16X3
+        return _lib.GEMM_BF16X6
+
+    def _auto_base(self) -> str:
         if self.news_embedding_dim % 80 != 0:
             return "bf16x6"
         ws = [m.weight for g in ("news", "user") for f in ("W", "ffn1", "ffn2") for m in getattr(self, f"{g}_graph_attention_{f}")]
@@ -251,7 +260,7 @@ class DIGAT(GraphEncoder):
                 | (8 if self.resolved_xattn_mode("news") == "sparse" else 0)
                 | (16 if pm in ("pq-bf16", "pq-bf16-x1") else 0)         # DIGAT_PQ_BF16: P', Q of Eq. 8 stored in bf16
                 | (32 if pm == "pq-bf16-x1" else 0)                      # DIGAT_PQ_X1: ... and computed with one bf16 product
-                | (_lib.PARAMS_GEMM_F16X3 if self.resolved_projection_mode() == "fp16x3" else 0))
+                | (_lib.PARAMS_GEMM_F16X3 if self.gemm_format() == _lib.GEMM_F16X3 else 0))
 
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention
@@ -259,7 +268,7 @@ class DIGAT(GraphEncoder):
                                                         self.user_news_Q.bias), (ua.K.weight, ua.Q.weight, ua.Q.bias))
 
     def _fold_key(self):
-        key = (self.training, self.resolved_projection_mode()) + tuple(t._version for trio in self._fold_sources() for t in trio)
+        key = (self.training, self.resolved_projection_mode(), self.gemm_format()) + tuple(t._version for trio in self._fold_sources() for t in trio)
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))

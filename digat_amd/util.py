@@ -153,7 +153,8 @@ def weights_key(encoder, dc: DeviceCorpus) -> tuple:
     (an optimizer step or ``load_state_dict`` bumps them) and the news representations they were computed from."""
     params = tuple((p.data_ptr(), p._version) for p in encoder.parameters()) if hasattr(encoder, "parameters") else ()
     pm = encoder.resolved_projection_mode() if hasattr(encoder, "resolved_projection_mode") else getattr(encoder, "projection_mode", None)
-    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm)
+    fmt = encoder.gemm_format() if hasattr(encoder, "gemm_format") else None
+    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt)
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
@@ -430,7 +431,7 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
         # an fp16x3 GEMM met an activation at or beyond the format's range (|x| >= 4094: node features of a deep layer, say):
         # its results are degraded or inf.  Under "auto" the run is redone in the range-free bf16x6 format (and stays there);
         # an explicit "fp16x3" is the caller's word against the data's — refuse to return such scores.
-        if enc.projection_mode != "auto":
+        if enc.projection_mode == "fp16x3":
             from ._lib import DigatHipError
             raise DigatHipError("projection_mode='fp16x3': an activation left the format's range (|x| >= 4094); use 'bf16x6' or 'auto'")
         import warnings

@@ -71,7 +71,10 @@ def metrics(sc):
 torch.set_num_threads(8)
 base = run(); mb = metrics(base)
 print("rows", corpus.rows, "fp32 metrics", mb, "score scale", np.abs(base).mean())
-for name, graphs_, hq in (("bf16", ("user",), False), ("bf16", ("user", "news"), False), ("fp8", ("user",), False), ("fp8", ("user", "news"), False), ("fp8p2", ("user",), False), ("fp8e5m2", ("user",), False)):
+ALL = (("bf16", ("user",), False), ("bf16", ("user", "news"), False), ("fp8", ("user",), False), ("fp8", ("user", "news"), False), ("fp8p2", ("user",), False), ("fp8e5m2", ("user",), False))
+ONLY = [a.split("=")[1].split(",") for a in sys.argv if a.startswith("--modes=")]
+for name, graphs_, hq in [m for m in ALL if not ONLY or (m[0] in ONLY[0] and m[1] == ("user",))]:
     STATE.update(q=MODES[name], graphs=graphs_, h=hq)
     sc = run(); m = metrics(sc)
+    sys.stdout.flush()
     print(f"{name:5s} graphs={graphs_} h_bf16={hq}: max rel score diff {np.max(np.abs(sc-base)/(np.abs(base)+1e-3)):.2e}  mean {np.mean(np.abs(sc-base)/(np.abs(base)+1e-3)):.2e}  metric drift {np.abs(m-mb).max():.2e} {np.round(m-mb,6)}")
