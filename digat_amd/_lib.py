@@ -24,7 +24,7 @@ _f = C.c_void_p  # every device pointer crosses as void*
 
 
 class LayerParams(C.Structure):
-    _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a", "wsplit")]
+    _fields_ = [(k, _f) for k in ("W", "bW", "F1", "F2", "F3", "b3", "a", "wsplit", "f3_wsplit")]
 
 
 class MsaParams(C.Structure):
@@ -48,7 +48,8 @@ class Params(C.Structure):
                                      "userAtt_K", "userAtt_Q", "userAtt_bQ")]
                 + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)]
                 + [(k, _f) for k in ("cand_fold_W", "cand_fold_b", "user_news_fold_W", "user_news_fold_b",
-                                     "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit", "range_flag")])
+                                     "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit", "cand_fold_wsplit", "gate_wsplit")]
+                + [("ctx_wsplit", _f * (DIGAT_MAX_DEPTH + 1)), ("range_flag", _f)])
 
 
 class DigatHipError(RuntimeError):

@@ -317,7 +317,7 @@ int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float*
     GemmArgs g = gemm_plain(x, ldx, w, b, y, ldy, M, N, K, 0);
     g.wsplit = (const unsigned short*)wsplit; g.format = format;
     if (g_train_bf16) g.x1_segs = 7;
-    if (M < 2048) return DIGAT_ERR_SHAPE;      // the bf16x6 kernel serves the big projections only
+    // M >= 2048: the strip-mined kernel; below: the skinny kernel on the same split image (gemm_skinny_split_kernel)
     return launch_gemm(g, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
 
@@ -515,6 +515,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             g.w[2] = p->user[next_layer].F3; g.bias[2] = p->user[next_layer].b3; g.y[2] = r_user2[next_layer & 1];
             g.nsegs = 3;
         }
+        g.wsplit = (const unsigned short*)p->ctx_wsplit[next_layer]; g.format = fmt; g.range_flag = rflag;   // NULL: fp32 MFMA
         return launch_gemm(g, sq);
     };
     // `live` (layers' outputs): the rows of dead nodes were never written — the topic pooling takes them as zero
@@ -534,13 +535,16 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     auto news_ctx = [&](const float* Xn_cur, hipStream_t sq) -> int {
         const long ldx = (long)N * d;
         float* kq = kq_t;                          // free here: the previous user context has consumed it
-        int e = launch_gemm(gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0), sq);
+        GemmArgs gq = gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0);
+        gq.wsplit = (const unsigned short*)p->cand_fold_wsplit; gq.format = fmt; gq.range_flag = rflag;
+        int e = launch_gemm(gq, sq);
         if (e) return e;
         e = launch_pool(Xn_cur, ldx, kq, Mn, nullptr, glob, B, N, d, sq);
         if (e) return e;
         GemmArgs g = gemm_plain(Xn_cur, ldx, p->news_graph_W, p->news_graph_b, c_n, d, B, d, 2 * d, 0);
         g.k0 = d; g.a1 = glob; g.lda1 = d;
         g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = c_n; g.lde2 = d;
+        g.wsplit = (const unsigned short*)p->gate_wsplit; g.format = fmt; g.range_flag = rflag;
         return launch_gemm(g, sq);
     };
 
@@ -792,7 +796,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
         // ---- news graph, Eq. 8 + context + the queries that follow from the new c_n (side stream)
-        rc = launch_gemm(gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0), sn);     // K3 of the news graph
+        {
+            GemmArgs g3 = gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0);              // K3 of the news graph
+            g3.wsplit = (const unsigned short*)ln.f3_wsplit; g3.format = fmt; g3.range_flag = rflag;
+            rc = launch_gemm(g3, sn);
+        }
         if (rc) return rc;
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
             const size_t ndn = (size_t)B * N * d;

@@ -197,6 +197,23 @@ class DIGAT(GraphEncoder):
             P._folds = self._fold_attention()
             (P.cand_fold_W, P.cand_fold_b, P.user_news_fold_W, P.user_news_fold_b,
              P.userAtt_fold_W, P.userAtt_fold_b) = (t.data_ptr() for t in P._folds)
+            if P._splits:
+                # the [B,d] linears of the folded path on split images too (gemm_skinny_split_kernel): K3 of the news graph,
+                # the candidate query, the gate, and per layer the three matrices applied to the news context
+                L_, d, dev = _lib.lib(), self.news_embedding_dim, self.topic_node_embedding.device
+
+                def image(rows, K, fn, *args):
+                    buf = torch.empty(L_.digat_split_weights_bytes(rows, K), dtype=torch.uint8, device=dev)
+                    _lib.check(fn(*args, buf.data_ptr(), fmt, _lib.stream_ptr()), "split")
+                    P._splits.append(buf)
+                    return buf.data_ptr()
+                for i in range(self.graph_depth):
+                    P.news[i].f3_wsplit = image(d, d, L_.digat_split_weights, self.news_graph_attention_ffn3[i].weight.data_ptr(), d, d)
+                P.cand_fold_wsplit = image(d, d, L_.digat_split_weights, P.cand_fold_W, d, d)
+                P.gate_wsplit = image(d, 2 * d, L_.digat_split_weights, self.news_graph_W.weight.data_ptr(), d, 2 * d)
+                for l in range(self.graph_depth + 1):
+                    third = self.user_graph_attention_ffn3[l].weight.data_ptr() if l < self.graph_depth else P.userAtt_fold_W
+                    P.ctx_wsplit[l] = image(3 * d, d, L_.digat_split_proj_weights, P.user_news_fold_W, P.userAtt_fold_W, third, d)
         self._param_block = (ptrs, P, self._fold_key())
         return P
 

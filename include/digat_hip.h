@@ -161,6 +161,9 @@ typedef struct digat_layer_params {
                                  32-deep K tile; digat_split_weights_bytes(3d, d) bytes).  Non-NULL runs the
                                  node projections as six bf16 MFMA products per fp32 product ("bf16x6":
                                  fp32-equivalent accuracy, 6/16 of the fp32-MFMA cost); NULL = fp32 MFMA. */
+    const void  *f3_wsplit;   /* optional: ffn3.weight split by digat_split_weights(F3, d, d, ...) in the block's format: K3 = ctx F3^T + b3
+                                 ([B,d] rows) then runs on the split image too (news graph; the user graph's F3 travels inside
+                                 digat_params.ctx_wsplit).  NULL = fp32 MFMA */
 } digat_layer_params;
 
 typedef struct digat_params {
@@ -184,6 +187,13 @@ typedef struct digat_params {
     const float *user_news_fold_W, *user_news_fold_b;
     const float *userAtt_fold_W, *userAtt_fold_b;
     const void  *featureAffine_wsplit;   /* optional: featureAffine.weight split by digat_split_weights (same format as the layers') */
+    /* Optional split images (the block's format) of the [B,d] linears of the folded inference path; NULL = fp32 MFMA for that one:
+     * cand_fold_wsplit: cand_fold_W [d,d]; gate_wsplit: news_graph_W [d,2d];
+     * ctx_wsplit[l], l = 0 .. depth: the three matrices applied to the news context before layer l, stacked
+     * [user_news_fold_W ; userAtt_fold_W ; user[l].F3] (3d rows; the last entry, l = depth, has no F3: 2d rows are read),
+     * each made by digat_split_proj_weights(user_news_fold_W, userAtt_fold_W, user[l].F3, d, ...). */
+    const void  *cand_fold_wsplit, *gate_wsplit;
+    const void  *ctx_wsplit[DIGAT_MAX_DEPTH + 1];
     uint32_t    *range_flag;             /* optional, DIGAT_PARAMS_GEMM_F16X3 only: one device word the fp16x3 GEMMs OR 1 into when an
                                             activation is at or beyond the format's range (|x| >= 4094, inf or NaN): the caller zeroes it
                                             before a scoring run and reads it after (digat_amd/util.py re-scores in bf16x6 when set) */

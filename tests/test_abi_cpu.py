@@ -44,12 +44,12 @@ def test_workspace_queries():
 
 
 def test_struct_layout_matches_header():
-    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 8 pointers + 6 folded-query pointers + 1 split-weight pointer
-    + the range-flag pointer."""
+    """digat_params: 4 int32 + 14 pointers + 2 * DIGAT_MAX_DEPTH * 9 pointers + 6 folded-query pointers + 1 split-weight pointer
+    + 2 + (DIGAT_MAX_DEPTH + 1) split images of the [B,d] linears + the range-flag pointer."""
     import ctypes
     from digat_amd import _lib
-    assert ctypes.sizeof(_lib.LayerParams) == 8 * 8
-    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 8 * 8 + 8 * 8
+    assert ctypes.sizeof(_lib.LayerParams) == 9 * 8
+    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 9 * 8 + 7 * 8 + 2 * 8 + 17 * 8 + 8
 
 
 def test_module_mirrors_reference_parameter_names():

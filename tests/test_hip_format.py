@@ -61,6 +61,34 @@ def test_mismatched_split_image_is_refused():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,N,K,fmt", [(1024, 400, 400, 1), (1024, 1200, 400, 1), (1000, 400, 800, 1), (37, 80, 40, 1), (1, 160, 72, 1),
+                                       (1024, 400, 400, 0), (700, 1200, 408, 0), (2047, 240, 64, 1)])
+def test_skinny_linear_on_split_images_is_fp32_grade(M, N, K, fmt):
+    """The [B,d] linears (M < 2048) on the weights' split images (gemm_skinny_split_kernel): against fp64 next to the fp32-MFMA
+    skinny kernel on the same data — mean and largest error at most 1.1x / 1.5x the fp32 chain's."""
+    from digat_amd import _lib
+    rng = np.random.default_rng(M + N + K + fmt)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    xd, wd, bd = (torch.from_numpy(a).to(DEV) for a in (x, w, b))
+    L = _lib.lib()
+    ys = torch.full((M, N), float("nan"), device=DEV)
+    y32 = torch.full((M, N), float("nan"), device=DEV)
+    ws = torch.empty(L.digat_split_weights_bytes(N, K), dtype=torch.uint8, device=DEV)
+    _lib.check(L.digat_linear_f32x3(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), ys.data_ptr(), N, M, N, K, ws.data_ptr(), fmt,
+                                    _lib.stream_ptr()), "digat_linear_f32x3")
+    _lib.check(L.digat_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y32.data_ptr(), N, M, N, K, _lib.stream_ptr()), "digat_linear_f32")
+    torch.cuda.synchronize()
+    es = np.abs(ys.cpu().numpy().astype(np.float64) - want)
+    e32 = np.abs(y32.cpu().numpy().astype(np.float64) - want)
+    print(f"\n[skinny split {M}x{N}x{K} fmt {fmt}] mean {es.mean():.3e} (fp32 chain {e32.mean():.3e}), max {es.max():.3e} ({e32.max():.3e})")
+    assert np.isfinite(es).all()
+    slack = 1.1 if K >= 256 else 1.5           # short sums: a few terms, the two roundings of the operand split show
+    assert es.mean() <= slack * e32.mean() + 1e-9 and es.max() <= 1.5 * e32.max() + 1e-7
+
+
 def test_fp16x3_range_flag_and_fallback_at_layers_above_zero():
     """Node features of layers >= 1 are X + relu(alpha h): with a large layer-0 W they leave fp16x3's range (|x| >= 4094) although
     the weights (< 32) and the corpus's news representations (< 256) pass the host-side guard.  The GEMM raises the device
