@@ -205,7 +205,7 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
         util.prepare_news_side(model.graph_encoder, dc, args.batch)     # SA gather + c_n0 + layer-0 tables (setup, untimed)
         torch.cuda.synchronize()
         W.setup_ms = (time.perf_counter() - t0) * 1e3
-    tables = {k: getattr(dc, k) for k in ("news_embedding", "SA_news_representations", "c_n0", "news_hpq0", "user_hpq0", "news_graph",
+    tables = {k: getattr(dc, k) for k in ("news_embedding", "SA_news_representations", "c_n0", "news_hpq0", "user_hpq0", "ctxq0", "news_graph",
                                           "user_graph", "history")}
     W.table_bytes = {k: int(v.numel() * v.element_size()) for k, v in tables.items() if v is not None}
     return W

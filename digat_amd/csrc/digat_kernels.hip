@@ -493,7 +493,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
-                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g) {
+                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;       // the format every wsplit image of `p` was split in
@@ -519,9 +519,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         return launch_gemm(g, sq);
     };
     // `live` (layers' outputs): the rows of dead nodes were never written — the topic pooling takes them as zero
+    // kq_topic / kq_user: the two queries derived from the news context (the workspace ones, or — initial context — the rows of the
+    // per-news table the caller gathered: ctxq0)
     auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr,
-                             const uint8_t* live = nullptr) -> int {
-        int e = launch_topic(Xu_cur, (long)U * d, kq_t, cat_idx, T, B, H, C1, d, sq, xgroup, live, U, live ? hist_last : nullptr);
+                             const uint8_t* live = nullptr, const float* kq_topic = nullptr, const float* kq_user = nullptr) -> int {
+        if (!kq_topic) { kq_topic = kq_t; kq_user = kq_u; }
+        int e = launch_topic(Xu_cur, (long)U * d, kq_topic, cat_idx, T, B, H, C1, d, sq, xgroup, live, U, live ? hist_last : nullptr);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);
         g.epi = EPI_RELU_RES; g.e0 = T; g.lde0 = d;
@@ -530,7 +533,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (bucket_idx && gemm_is_bf16x6(g)) { g.rowidx = bucket_idx; g.nrows_dev = nbuckets_dev; }   // unmasked buckets only
         e = launch_gemm(g, sq);
         if (e) return e;
-        return launch_pool(T2, (long)C1 * d, kq_u, cat_mask, addend, c_u, B, C1, d, sq);
+        return launch_pool(T2, (long)C1 * d, kq_user, cat_mask, addend, c_u, B, C1, d, sq);
     };
     auto news_ctx = [&](const float* Xn_cur, hipStream_t sq) -> int {
         const long ldx = (long)N * d;
@@ -708,16 +711,22 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rc = news_project(0, Xn_in, side ? side->s : st);
         if (rc) return rc;
     }
-    rc = from_c_n(0, st);
-    if (rc) return rc;
-    rc = user_ctx_tail(xu0_grouped ? Xg0 : Xu[0], nullptr, st, xu0_grouped ? row_group : nullptr);        // c_u (:192)
+    // [kq_topic | kq_user | K3 of the user graph's layer 0] are functions of the candidate's cached c_n0: a caller that keeps them
+    // per news (digat_news_context_queries, next to c_n0 itself) hands over the batch's rows and the first link of the chain goes
+    const size_t bd = (size_t)B * d;
+    if (!ctxq0) {
+        rc = from_c_n(0, st);
+        if (rc) return rc;
+    }
+    rc = user_ctx_tail(xu0_grouped ? Xg0 : Xu[0], nullptr, st, xu0_grouped ? row_group : nullptr, nullptr,
+                       ctxq0 ? ctxq0 : nullptr, ctxq0 ? ctxq0 + bd : nullptr);        // c_u (:192)
     if (rc) return rc;
     const float* xn_cur = Xn_in;
     int un = 0, nn = 0;
     for (int i = 0; i < L; ++i) {
         const digat_layer_params& ln = p->news[i];
         const digat_layer_params& lu = p->user[i];
-        const float* r_user = r_user2[i & 1];     // K3 of the user graph, from the previous c_n
+        const float* r_user = (i == 0 && ctxq0 && L > 0) ? ctxq0 + 2 * bd : r_user2[i & 1];     // K3 of the user graph, from the previous c_n
         hipStream_t sn = side ? side->s : st;
         if (side && i == 0) {                      // the news chain starts from the initial c_u (caller's stream)
             if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(sn, side->fork, 0) != hipSuccess)
@@ -868,7 +877,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             const float* c_n0, float* out_news, float* out_user, int B, int N, int H,
                             void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
                             const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
-                            const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr) {
+                            const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr,
+                            const float* ctxq0 = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -932,7 +942,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g);
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g,
+                                  c_n0 ? ctxq0 : nullptr);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -1008,7 +1019,8 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
                                     const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
                                     const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
                                     int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream,
-                                    const float* news_hpq0, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr) {
+                                    const float* news_hpq0, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
+                                    const float* ctxq0 = nullptr) {
     if (!p || !ue_g || !Au_g || !cat_mask_g || !cat_idx_g || !row_group || !workspace || G <= 0) return DIGAT_ERR_ARG;
     const int d = p->d, C = p->category_num, U = H + C;
     if (!p->cand_fold_W || !p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;   // grouped = folded path
@@ -1030,7 +1042,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g);
+                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g, ctxq0);
 }
 
 int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
@@ -1044,12 +1056,31 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
 int digat_encoder_fwd_grouped_cached(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                                      const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
                                      const int32_t* row_group, const float* c_n0, const float* news_hpq0,
-                                     const float* hist_hpq0, const float* topic_hpq0, float* out_news,
+                                     const float* hist_hpq0, const float* topic_hpq0, const float* ctxq0, float* out_news,
                                      float* out_user, int B, int G, int N, int H, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     if ((hist_hpq0 == nullptr) != (topic_hpq0 == nullptr)) return DIGAT_ERR_ARG;
+    if (ctxq0 && !c_n0) return DIGAT_ERR_ARG;           // the queries belong to a given news context
     return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
-                                    workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0);
+                                    workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0, ctxq0);
+}
+
+int digat_news_context_queries(const digat_params* p, const float* c_n, float* out, int M, void* stream) {
+    if (!p || !c_n || !out || M < 0) return DIGAT_ERR_ARG;
+    if (!p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;          // folded inference path only
+    const int d = p->d, L = p->depth;
+    if (d <= 0 || d % 4) return DIGAT_ERR_SHAPE;
+    if (M == 0) return DIGAT_OK;
+    const size_t md = (size_t)M * d;
+    // exactly the launch the encoder makes from the batch's c_n0 before layer 0 (rows are independent of the batch they sit in)
+    GemmArgs g = gemm_plain(c_n, d, p->user_news_fold_W, p->user_news_fold_b, out, d, M, d, d, 0);
+    g.w[1] = p->userAtt_fold_W; g.bias[1] = p->userAtt_fold_b; g.y[1] = out + md;
+    g.nsegs = 2;
+    if (L > 0) { g.w[2] = p->user[0].F3; g.bias[2] = p->user[0].b3; g.y[2] = out + 2 * md; g.nsegs = 3; }
+    g.wsplit = (const unsigned short*)p->ctx_wsplit[0];
+    g.format = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0; g.range_flag = g.format ? (unsigned*)p->range_flag : nullptr;
+    g.m_dispatch = 1;                      // the [B,d] kernel whatever M is: the same bits as inside a batch
+    return launch_gemm(g, (hipStream_t)stream);
 }
 
 int digat_user_project0(const digat_params* p, const float* X, float* hpq, int M, void* stream) {

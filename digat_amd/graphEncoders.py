@@ -453,9 +453,24 @@ class DIGAT(GraphEncoder):
                        "digat_user_project0")
         return out
 
+    def news_context_queries(self, news_graph_context):
+        """[topic query | user-attention query | K3 of the user graph's layer 0] of M news contexts ([M,d] -> [3,M,d]): linear maps
+        of the candidate's cached c_n0, so a driver keeps them per news next to c_n0 (``util.prepare_news_side``) and hands the
+        batch's rows to ``inference_grouped(ctxq0=...)``.  Same launch, same bits as inside the encoder (eval mode)."""
+        c = _lib.f32(news_graph_context)
+        dev = _lib.require_device(c)
+        M, d = c.shape
+        out = torch.empty((3, M, d), dtype=torch.float32, device=dev)
+        if self.graph_depth == 0:
+            out[2].zero_()
+        if M:
+            _lib.check(_lib.lib().digat_news_context_queries(self._params(), c.data_ptr(), out.data_ptr(), M, _lib.stream_ptr()),
+                       "digat_news_context_queries")
+        return out
+
     def inference_grouped(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                           user_category_mask, user_category_indices, row_group, news_graph_context, news_hpq0=None,
-                          hist_hpq0=None, topic_hpq0=None):
+                          hist_hpq0=None, topic_hpq0=None, ctxq0=None):
         """``inference`` for rows that share users (not in the reference: its driver expands the user tensors per
         row, util.py:57-67).  The four user tensors are given once per GROUP ([G,...]) and ``row_group`` [B] maps
         each row to its group; results are bit-identical to ``inference`` on the expanded tensors."""
@@ -481,8 +496,12 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
-        if news_hpq0 is not None or hist_hpq0 is not None:
-            hpq = hh = th = None
+        if news_hpq0 is not None or hist_hpq0 is not None or ctxq0 is not None:
+            hpq = hh = th = cq = None
+            if ctxq0 is not None:
+                cq = _lib.f32(ctxq0)
+                if tuple(cq.shape) != (3, B, d):
+                    raise ValueError("ctxq0 must be [3, B, d] (news_context_queries of the batch's news contexts)")
             if news_hpq0 is not None:
                 hpq = _lib.f32(news_hpq0)
                 if tuple(hpq.shape) != (3, B, N, d):
@@ -493,7 +512,7 @@ class DIGAT(GraphEncoder):
                     raise ValueError("hist_hpq0 must be [3, G, H, d] and topic_hpq0 [3, C, d] (project_user_layer0)")
             _lib.check(L.digat_encoder_fwd_grouped_cached(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(),
                                                           Au.data_ptr(), cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(),
-                                                          _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), out_n.data_ptr(),
+                                                          _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), _lib.ptr(cq), out_n.data_ptr(),
                                                           out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),
                        "digat_encoder_fwd_grouped_cached")
             return out_n, out_u

@@ -44,6 +44,7 @@ class DeviceCorpus:
     news_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, N, d]: layer 0's [h|P|Q] of every news graph
     user_hpq0: Optional[torch.Tensor] = None                 # [3, news_num, d]: layer 0's user-graph [h|P|Q] of every news as a history node
     topic_hpq0: Optional[torch.Tensor] = None                # [3, C, d]: ... of the topic nodes
+    ctxq0: Optional[torch.Tensor] = None                     # [3, news_num, d]: topic query | user query | layer-0 user K3 of every c_n0
     weights_key: Optional[tuple] = None                      # the weight version the five caches above were computed from
     title_text: Optional[torch.Tensor] = None                # [news_num, Lw] int32 token ids (MIND_corpus.py: news_title_text)
     title_mask: Optional[torch.Tensor] = None                # [news_num, Lw] bool                       (news_title_mask)
@@ -145,6 +146,11 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
         with torch.no_grad():
             dc.user_hpq0 = encoder.project_user_layer0(dc.news_embedding)
             dc.topic_hpq0 = encoder.project_user_layer0(encoder.topic_node_embedding.detach())
+    # ... and the first link of the [B,d] chain: the two queries and the user graph's layer-0 K3 are linear maps of c_n0
+    dc.ctxq0 = None
+    if hasattr(encoder, "news_context_queries") and not getattr(encoder, "training", False) and d % 4 == 0:
+        with torch.no_grad():
+            dc.ctxq0 = encoder.news_context_queries(dc.c_n0)
     dc.weights_key = weights_key(encoder, dc)
 
 
@@ -222,7 +228,8 @@ class GroupedBatchPipeline:
                         news_mask=torch.empty((B, N), dtype=dc.news_graph_mask.dtype, device=dev),
                         c_n0=torch.empty((B, d), dtype=torch.float32, device=dev),
                         hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None else None),
-                        hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None))
+                        hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None),
+                        ctxq=(torch.empty((3 * B * d,), dtype=torch.float32, device=dev) if dc.ctxq0 is not None else None))
         self.sets = [bufs() for _ in range(nsets)]
         uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
         for s, e in self.batches:
@@ -282,6 +289,9 @@ class GroupedBatchPipeline:
             if b["hist_hpq"] is not None:
                 for t in range(3):             # [3, G*H, d] <- user_hpq0[t][history of the impression]
                     job(dc.user_hpq0[t].data_ptr(), b["hist_hpq"].data_ptr() + 4 * t * G * H * d, d * 4, G * H, uniq_ptr, hist_tab, H)
+            if b["ctxq"] is not None:
+                for t in range(3):             # [3, n, d] <- ctxq0[t][candidate]
+                    job(dc.ctxq0[t].data_ptr(), b["ctxq"].data_ptr() + 4 * t * n * d, d * 4, n, cand_ptr)
             if b["hpq"] is not None:
                 for t in range(3):             # contiguous [3, n, N, d] for this batch's n rows
                     job(dc.news_hpq0[t].data_ptr(), b["hpq"].data_ptr() + 4 * t * n * N * d, N * d * 4, n, cand_ptr)
@@ -306,8 +316,9 @@ class GroupedBatchPipeline:
         H_ = b["hist"].shape[1]
         news_hpq = b["hpq"][:3 * n * N_ * d_].view(3, n, N_, d_) if b["hpq"] is not None else None
         hist_hpq = b["hist_hpq"][:3 * G * H_ * d_].view(3, G, H_, d_) if b["hist_hpq"] is not None else None
-        if news_hpq is not None or hist_hpq is not None:
-            out = out + (news_hpq, hist_hpq, self.dc.topic_hpq0 if hist_hpq is not None else None)
+        ctxq = b["ctxq"][:3 * n * d_].view(3, n, d_) if b["ctxq"] is not None else None
+        if news_hpq is not None or hist_hpq is not None or ctxq is not None:
+            out = out + (news_hpq, hist_hpq, self.dc.topic_hpq0 if hist_hpq is not None else None, ctxq)
         return out
 
     def scored(self, k):

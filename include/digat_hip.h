@@ -273,12 +273,17 @@ int digat_news_project0(const digat_params* params, const float* Xn, float* hpq,
  * the groups' [h|P|Q] from them instead of running the projection GEMM (used when B*U >= 2048: below that the in-batch
  * launch is another kernel).  Bit-identical. */
 int digat_user_project0(const digat_params* params, const float* X, float* hpq, int M, void* stream);
+/* The first link of the [B,d] chain — the topic query, the user-attention query and the user graph's layer-0 K3, all three linear
+ * maps of the candidate's cached news context c_n0 (graphEncoders.py:126,133,169 with news_graph_context given, :189) — depends on
+ * the news alone.  digat_news_context_queries: c_n [M,d] -> out [3][M,d] (the encoder's own launch, row by row; folded path), kept
+ * per news next to c_n0; the cached entry takes the batch's rows ctxq0 [3][B,d] (or NULL) and skips that launch.  Bit-identical. */
+int digat_news_context_queries(const digat_params* params, const float* c_n, float* out, int M, void* stream);
 int digat_encoder_fwd_grouped_cached(const digat_params* params,
                                      const float* news_graph_embeddings, const uint8_t* news_graph, const uint8_t* news_graph_mask,
                                      const float* user_news_embedding_g, const uint8_t* user_graph_g,
                                      const uint8_t* user_category_mask_g, const int64_t* user_category_indices_g,
                                      const int32_t* row_group, const float* news_graph_context, const float* news_hpq0,
-                                     const float* hist_hpq0, const float* topic_hpq0,
+                                     const float* hist_hpq0, const float* topic_hpq0, const float* ctxq0,
                                      float* out_news, float* out_user, int B, int G, int N, int H,
                                      void* workspace, size_t workspace_bytes, void* stream);
 

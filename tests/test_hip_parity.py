@@ -736,8 +736,13 @@ def test_cached_news_projections_reproduce_the_in_batch_bits():
     util.prepare_news_side(model.graph_encoder, dc, 512)
     assert dc.news_hpq0 is not None and tuple(dc.news_hpq0.shape) == (3, 1500, spec.news_graph_size, spec.embedding_dim)
     assert tuple(dc.user_hpq0.shape) == (3, 1500, spec.embedding_dim) and tuple(dc.topic_hpq0.shape) == (3, spec.category_num, spec.embedding_dim)
+    assert tuple(dc.ctxq0.shape) == (3, 1500, spec.embedding_dim)      # topic query | user query | layer-0 user K3 per news
     with_tables = util.score_rows(model, dc, 0, dc.rows, 512)
     saved = (dc.news_hpq0, dc.user_hpq0, dc.topic_hpq0)
+    saved_q, dc.ctxq0 = dc.ctxq0, None
+    no_queries = util.score_rows(model, dc, 0, dc.rows, 512)
+    assert torch.equal(with_tables, no_queries)
+    dc.ctxq0 = saved_q
     dc.user_hpq0 = dc.topic_hpq0 = None
     news_only = util.score_rows(model, dc, 0, dc.rows, 512)
     dc.news_hpq0 = None
