@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
-B="python3 $ROOT/bench.py --extra-steps 0 --cpu-rows 0 --steps 30"
+B="python3 $ROOT/bench.py --extra-steps 0 --cpu-rows 0 --steps 30 --e2e-impressions 0"
 # the traced run records its event pairs on EVERY step of the timed region, so that the library's averages and the trace's
 # (tools/trace_region.py, below) are over the same launches
 DIGAT_BENCH_PROFILE_EVERY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_traced.json 2> $OUT/trace.err
@@ -18,13 +18,16 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $B --st
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_mfma -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_mfma.err
-# the LDS-staged pipelined Eq. 8 kernel (opt-in): its HBM traffic
-DIGAT_XATTN_STAGED=1 DIGAT_STAGED_CFG=4 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_stream -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fs.err
-DIGAT_XATTN_STAGED=1 DIGAT_STAGED_CFG=4 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_stream -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_ws.err
 cd $ROOT
 python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma --match gemm_bf16x6s > $OUT/gemm_pmc.txt 2>&1
 python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write --match xattn_sparse > $OUT/sparse_pmc.txt 2>&1
-python3 tools/pmc_table.py $OUT/pmc_fetch_stream $OUT/pmc_write_stream --match xattn_stream > $OUT/stream_pmc.txt 2>&1
+python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write --match xattn_small_lds > $OUT/news_pmc.txt 2>&1
+python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write --match gemm_skinny_split > $OUT/skinny_pmc.txt 2>&1
+python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write --match topic_pool > $OUT/topic_pmc.txt 2>&1
+# configs[2] / configs[3]: kernel stats of the stress and MIND-large workloads (single-stream trace, grouped by kernel and grid)
+bash tools/exp/solo_trace.sh $OUT/stress --workload mind-small-stress --impressions 4096 > $OUT/stress_solo_kernels.txt 2>&1
+bash tools/exp/solo_trace.sh $OUT/large --workload mind-large-default --impressions 4096 > $OUT/large_solo_kernels.txt 2>&1
+bash tools/exp/solo_trace.sh $OUT/default_solo > $OUT/default_solo_kernels.txt 2>&1
 python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
 # per-kernel averages of the traced run's TIMED REGION only (between bench.py's two marker kernels), next to that run's own line
 python3 tools/trace_region.py $OUT/trace/t_kernel_trace.csv > $OUT/timed_region_kernels.txt 2>&1
