@@ -672,8 +672,8 @@ def run_e2e(args, D):
     t3 = clock()
     ranks, metrics = evaluate.device_ranks_and_metrics(scores, row_imp, corpus.row_label)                            # :70-80, evaluate.py
     t4 = clock()
-    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=True) as f:                                          # :81-84
-        f.write("\n".join(evaluate.rank_lines(ranks, row_imp)))
+    with tempfile.NamedTemporaryFile("wb", suffix=".txt", delete=True) as f:                                         # :81-84
+        f.write(evaluate.rank_file_bytes(ranks, row_imp))
         f.flush()
         rank_file_bytes = os.path.getsize(f.name)
     t5 = time.perf_counter()

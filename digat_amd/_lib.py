@@ -82,6 +82,7 @@ _SIGNATURES = {
     "digat_gather_tables": (C.c_int, [C.POINTER(GatherJob), C.c_int, _f]),
     "digat_profile_live_row_fraction": (C.c_double, []),
     "digat_rank_metrics": (C.c_int, [_f] * 3 + [C.c_int] + [_f] * 4),
+    "digat_format_rank_file": (C.c_int64, [_f, _f, C.c_int64, _f, C.c_int64]),
     "digat_gat_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_gat_fwd": (C.c_int, [_f] * 7 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_gat_train_save_bytes": (C.c_size_t, [C.c_int] * 3),

@@ -66,6 +66,25 @@ def scoring(labels: np.ndarray, ranks: np.ndarray, row_impression: np.ndarray) -
     return float(np.mean(aucs)), float(np.mean(mrrs)), float(np.mean(n5)), float(np.mean(n10))
 
 
+def rank_file_bytes(ranks: np.ndarray, row_impression: np.ndarray) -> bytes:
+    """``"\\n".join(rank_lines(ranks, row_impression))`` as bytes, formatted by the library's host-side C routine
+    (``digat_format_rank_file``): the Python loop spends 0.3 s of a 3 s MIND-small dev run on 2.7 M integers."""
+    import ctypes
+    from . import _lib
+    imp = np.asarray(row_impression, dtype=np.int64)
+    r = np.ascontiguousarray(ranks, dtype=np.int64)
+    if imp.size == 0:
+        return b""
+    count = int(imp[-1]) + 1
+    starts = np.ascontiguousarray(np.r_[0, np.cumsum(np.bincount(imp, minlength=count))], dtype=np.int64)
+    L = _lib.lib()
+    need = L.digat_format_rank_file(r.ctypes.data, starts.ctypes.data, count, None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    got = L.digat_format_rank_file(r.ctypes.data, starts.ctypes.data, count, ctypes.addressof(buf), need)
+    assert got == need
+    return buf.raw[:got]
+
+
 def device_ranks_and_metrics(scores, row_impression: np.ndarray, labels: np.ndarray = None):
     """Ranks (and, with labels, the four metrics) computed on the GPU by ``digat_rank_metrics``.
 

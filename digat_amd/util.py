@@ -464,6 +464,6 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
         ranks = evaluate.impression_ranks(scores_np, row_imp)
         metrics = evaluate.scoring(labels, ranks, row_imp) if labels is not None else None
     if result_file is not None:
-        with open(result_file, "w", encoding="utf-8") as f:
-            f.write("\n".join(evaluate.rank_lines(ranks, row_imp)))
+        with open(result_file, "wb") as f:
+            f.write(evaluate.rank_file_bytes(ranks, row_imp))
     return scores_np, metrics

@@ -416,6 +416,12 @@ int digat_user_ctx_bwd(const float* dout, const float* Xu, const uint8_t* cat_ma
 int digat_rank_metrics(const float* scores, const uint8_t* labels, const int64_t* impression_start, int num_impressions,
                        int32_t* ranks, double* per_impression, double* mean4, void* stream);
 
+/* The rank file of util.py:74-84 as bytes, formatted on the HOST (no GPU work): "<impression id> [r1,r2,...]" per line for ids
+ * 1 .. impressions ("[]" for an id without rows), lines joined by '\n', no trailing newline.  ranks [R] int64 (1-based ranks in
+ * row order), starts [impressions + 1] int64 row ranges.  Returns the number of bytes written, or — when out is NULL or cap is too
+ * small — the capacity needed. */
+int64_t digat_format_rank_file(const int64_t* ranks, const int64_t* starts, int64_t impressions, char* out, int64_t cap);
+
 /* ---- vanilla-GAT update layer of the ablation encoders -----------------------------------------
  * graphEncoders.py:493-519 (wo_interaction), :641-651 (News_graph_wo_inter), :788-798 (User_graph_wo_inter), eval mode:
  * h = X W^T + bW; e_ij = leaky_relu_0.2(a1.h_j + a2.h_i); -1e9 where A_ij = 0; alpha = softmax_j; out = relu(alpha h) + X.

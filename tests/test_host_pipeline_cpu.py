@@ -101,3 +101,22 @@ def test_two_rank_gloo_gather_equals_single_process():
     np.testing.assert_array_equal(results[1][0], want_scores)       # all_gather: every rank holds all scores
     assert results[1][1] is None                                    # metrics on rank 0 only
     np.testing.assert_allclose(results[0][1], want_metrics, rtol=0, atol=0)
+
+
+def test_rank_file_bytes_equal_the_joined_rank_lines():
+    """evaluate.rank_file_bytes (the library's host-side C formatter) against "\\n".join(rank_lines(...)): impressions without
+    rows, one-row impressions, three-digit ranks, six-digit ids."""
+    from digat_amd import evaluate
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        cnt = rng.integers(1, 320, size=1200)
+        if trial == 1:
+            cnt[[5, 100, 1199]] = 0
+        imp = np.repeat(np.arange(len(cnt)), cnt)
+        ranks = rng.integers(1, 400, size=len(imp)).astype(np.int64)
+        if trial == 2:
+            imp, ranks = np.repeat(np.arange(3), [2, 0, 3]), np.array([1, 2, 10, 3, 100])
+        if trial == 3:
+            imp, ranks = np.array([0, 0, 123456]), np.array([2, 1, 1])
+        assert evaluate.rank_file_bytes(ranks, imp) == "\n".join(evaluate.rank_lines(ranks, imp)).encode()
+    assert evaluate.rank_file_bytes(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)) == b""
