@@ -493,7 +493,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
-                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0) {
+                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
+                              const int64_t* news_index, int64_t news_rows) {
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;       // the format every wsplit image of `p` was split in
@@ -814,9 +815,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
             const size_t ndn = (size_t)B * N * d;
             const float* hn = (i == 0 && news_hpq0) ? news_hpq0 : (const float*)xws_news;
+            // layer 0 with news_index: h | P | Q and the nodes themselves are the per-news TABLES, read in place through the index
+            const bool tab = i == 0 && news_hpq0 && news_index;
+            const size_t plane = tab ? (size_t)news_rows * N * d : ndn;
             float* alpha_n = (float*)((char*)xws_news + align_up(3 * ndn * 4, 256) + align_up((size_t)B * d * 4, 256));
-            rc = launch_xattn_pairwise(hn + ndn, hn + 2 * ndn, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
-                                       false);
+            rc = launch_xattn_pairwise(hn + plane, hn + 2 * plane, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
+                                       false, nullptr, tab ? news_index : nullptr);
         } else {
             // larger news graphs (N = 26 / 65: the breadth-first SAG, a few entries per node) take the sparse kernel when the
             // caller says so (flags bit 3); there is no device-side decision for this graph
@@ -878,7 +882,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
                             const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
                             const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr,
-                            const float* ctxq0 = nullptr) {
+                            const float* ctxq0 = nullptr, const int64_t* news_index = nullptr, int64_t news_rows = 0) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -887,6 +891,10 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         return DIGAT_ERR_SHAPE;
     if (workspace_bytes < digat_encoder_workspace_bytes(B, N, H, C, d, L)) return DIGAT_ERR_WORKSPACE;
     if (B == 0) return DIGAT_OK;
+    // per-news tables read in place: only where layer 0 of the news graph is the one reader of the node table (given c_n0,
+    // cached projections, the small-graph kernel)
+    if (news_index && !(c_n0 && news_hpq0 && L > 0 && N <= 16 && d / 4 <= 256 && news_rows > 0 &&
+                        p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)) return DIGAT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
 
     char* ws = (char*)workspace;
@@ -943,7 +951,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
                                   xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g,
-                                  c_n0 ? ctxq0 : nullptr);
+                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -1020,7 +1028,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
                                     const int32_t* row_group, const float* c_n0, float* out_news, float* out_user,
                                     int B, int G, int N, int H, void* workspace, size_t workspace_bytes, void* stream,
                                     const float* news_hpq0, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
-                                    const float* ctxq0 = nullptr) {
+                                    const float* ctxq0 = nullptr, const int64_t* news_index = nullptr, int64_t news_rows = 0) {
     if (!p || !ue_g || !Au_g || !cat_mask_g || !cat_idx_g || !row_group || !workspace || G <= 0) return DIGAT_ERR_ARG;
     const int d = p->d, C = p->category_num, U = H + C;
     if (!p->cand_fold_W || !p->user_news_fold_W || !p->userAtt_fold_W) return DIGAT_ERR_ARG;   // grouped = folded path
@@ -1042,7 +1050,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g, ctxq0);
+                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g, ctxq0, news_index, news_rows);
 }
 
 int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
@@ -1056,13 +1064,14 @@ int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const u
 int digat_encoder_fwd_grouped_cached(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                                      const float* ue_g, const uint8_t* Au_g, const uint8_t* cat_mask_g, const int64_t* cat_idx_g,
                                      const int32_t* row_group, const float* c_n0, const float* news_hpq0,
-                                     const float* hist_hpq0, const float* topic_hpq0, const float* ctxq0, float* out_news,
+                                     const float* hist_hpq0, const float* topic_hpq0, const float* ctxq0,
+                                     const int64_t* news_index, int64_t news_rows, float* out_news,
                                      float* out_user, int B, int G, int N, int H, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     if ((hist_hpq0 == nullptr) != (topic_hpq0 == nullptr)) return DIGAT_ERR_ARG;
     if (ctxq0 && !c_n0) return DIGAT_ERR_ARG;           // the queries belong to a given news context
     return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
-                                    workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0, ctxq0);
+                                    workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0, ctxq0, news_index, news_rows);
 }
 
 int digat_news_context_queries(const digat_params* p, const float* c_n, float* out, int M, void* stream) {

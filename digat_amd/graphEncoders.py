@@ -470,18 +470,25 @@ class DIGAT(GraphEncoder):
 
     def inference_grouped(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                           user_category_mask, user_category_indices, row_group, news_graph_context, news_hpq0=None,
-                          hist_hpq0=None, topic_hpq0=None, ctxq0=None):
+                          hist_hpq0=None, topic_hpq0=None, ctxq0=None, news_index=None):
         """``inference`` for rows that share users (not in the reference: its driver expands the user tensors per
         row, util.py:57-67).  The four user tensors are given once per GROUP ([G,...]) and ``row_group`` [B] maps
-        each row to its group; results are bit-identical to ``inference`` on the expanded tensors."""
+        each row to its group; results are bit-identical to ``inference`` on the expanded tensors.
+        ``news_index`` [B] int64: ``news_graph_embeddings`` and ``news_hpq0`` are then the per-news TABLES ([news_num, N, d],
+        [3, news_num, N, d]) and row b reads their row ``news_index[b]`` in place (no gathered copies)."""
         Xn, ue = _lib.f32(news_graph_embeddings), _lib.f32(user_news_embedding)
         dev = _lib.require_device(Xn, news_graph, news_graph_mask, ue, user_graph, user_category_mask,
                                   user_category_indices, row_group)
-        B, N, d = Xn.shape
+        _, N, d = Xn.shape
+        B = news_graph.shape[0]
+        if news_index is None and Xn.shape[0] != B:
+            raise ValueError("news_graph_embeddings must have one graph per row (or pass news_index with the per-news tables)")
         G = ue.shape[0]
         H, C = self.max_history_num, self.category_num - 1
         if B == 0 or 4 * G > B or self.training:       # empty batch, or too few rows per group to pay off: expand, plain path
             rg = row_group.long()
+            if news_index is not None:
+                Xn = Xn.index_select(0, news_index.long())
             return self.inference(Xn, news_graph, news_graph_mask, ue.index_select(0, rg), user_graph.index_select(0, rg),
                                   user_category_mask.index_select(0, rg), user_category_indices.index_select(0, rg),
                                   news_graph_context)
@@ -496,15 +503,23 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
-        if news_hpq0 is not None or hist_hpq0 is not None or ctxq0 is not None:
-            hpq = hh = th = cq = None
+        if news_hpq0 is not None or hist_hpq0 is not None or ctxq0 is not None or news_index is not None:
+            hpq = hh = th = cq = ni = None
+            M = 0
+            if news_index is not None:
+                if news_hpq0 is None or news_graph_context is None:
+                    raise ValueError("news_index needs news_hpq0 (the per-news table) and news_graph_context")
+                ni = news_index.to(torch.int64).contiguous()
+                M = Xn.shape[0]
+                if ni.shape[0] != B or tuple(news_hpq0.shape) != (3, M, N, d):
+                    raise ValueError("with news_index: news_graph_embeddings [M, N, d], news_hpq0 [3, M, N, d], news_index [B]")
             if ctxq0 is not None:
                 cq = _lib.f32(ctxq0)
                 if tuple(cq.shape) != (3, B, d):
                     raise ValueError("ctxq0 must be [3, B, d] (news_context_queries of the batch's news contexts)")
             if news_hpq0 is not None:
                 hpq = _lib.f32(news_hpq0)
-                if tuple(hpq.shape) != (3, B, N, d):
+                if ni is None and tuple(hpq.shape) != (3, B, N, d):
                     raise ValueError("news_hpq0 must be [3, B, N, d] (project_news_layer0 of the batch's candidates)")
             if hist_hpq0 is not None:
                 hh, th = _lib.f32(hist_hpq0), _lib.f32(topic_hpq0)
@@ -512,7 +527,8 @@ class DIGAT(GraphEncoder):
                     raise ValueError("hist_hpq0 must be [3, G, H, d] and topic_hpq0 [3, C, d] (project_user_layer0)")
             _lib.check(L.digat_encoder_fwd_grouped_cached(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(),
                                                           Au.data_ptr(), cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(),
-                                                          _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), _lib.ptr(cq), out_n.data_ptr(),
+                                                          _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), _lib.ptr(cq), _lib.ptr(ni), M,
+                                                          out_n.data_ptr(),
                                                           out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),
                        "digat_encoder_fwd_grouped_cached")
             return out_n, out_u

@@ -86,11 +86,11 @@ class Model(nn.Module):
 
     def inference_grouped(self, user_news_embedding, user_graph, user_category_mask, user_category_indices, row_group,
                           candidate_news_embedding, news_graph, news_graph_mask, c_n0, news_hpq0=None, hist_hpq0=None,
-                          topic_hpq0=None, ctxq0=None):
+                          topic_hpq0=None, ctxq0=None, news_index=None):
         """``inference`` with the user tensors given once per impression ([G,...]) + ``row_group`` [B]; optional rows of the
         per-news layer-0 projection tables (``DIGAT.project_news_layer0`` / ``project_user_layer0``)."""
-        kw = {k: v for k, v in (("news_hpq0", news_hpq0), ("hist_hpq0", hist_hpq0), ("topic_hpq0", topic_hpq0), ("ctxq0", ctxq0))
-              if v is not None}
+        kw = {k: v for k, v in (("news_hpq0", news_hpq0), ("hist_hpq0", hist_hpq0), ("topic_hpq0", topic_hpq0), ("ctxq0", ctxq0),
+                                ("news_index", news_index)) if v is not None}
         news_rep, user_rep = self.graph_encoder.inference_grouped(candidate_news_embedding, news_graph, news_graph_mask,
                                                                   user_news_embedding, user_graph, user_category_mask,
                                                                   user_category_indices, row_group, c_n0, **kw)

@@ -206,7 +206,7 @@ class GroupedBatchPipeline:
     scored, so at most ``nsets`` batches are in flight: a driver that alternates over n streams wants nsets = n
     (``score_rows`` passes its lane count; with two sets a third lane only overlapped its prologue)."""
 
-    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray, nsets: int = 2):
+    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray, nsets: int = 2, in_place_tables: bool = True):
         self.dc, self.batches = dc, list(batches)
         self.nsets = nsets = max(2, int(nsets))
         dev = dc.news_embedding.device
@@ -217,19 +217,26 @@ class GroupedBatchPipeline:
         U, C1 = dc.user_graph.shape[1], dc.user_category_mask.shape[1]
         N = dc.news_graph.shape[1]
 
+        import os
+        in_place_tables = in_place_tables and os.environ.get("DIGAT_IN_PLACE", "1") != "0"          # A/B switch for measurements
+        in_place = dc.news_hpq0 is not None and N <= 16 and d % 4 == 0 and d <= 1024 and in_place_tables
+
         def bufs():
             return dict(hist=torch.empty((Gmax, H), dtype=torch.int64, device=dev),
                         user_rep=torch.empty((Gmax, H, d), dtype=torch.float32, device=dev),
                         user_graph=torch.empty((Gmax, U, U), dtype=dc.user_graph.dtype, device=dev),
                         cat_mask=torch.empty((Gmax, C1), dtype=dc.user_category_mask.dtype, device=dev),
                         cat_idx=torch.empty((Gmax, H), dtype=torch.int64, device=dev),
-                        sa=torch.empty((B, N, d), dtype=torch.float32, device=dev),
+                        sa=(torch.empty((B, N, d), dtype=torch.float32, device=dev) if not in_place else None),
                         news_graph=torch.empty((B, N, N), dtype=dc.news_graph.dtype, device=dev),
                         news_mask=torch.empty((B, N), dtype=dc.news_graph_mask.dtype, device=dev),
                         c_n0=torch.empty((B, d), dtype=torch.float32, device=dev),
-                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None else None),
+                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None and not in_place else None),
                         hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None),
                         ctxq=(torch.empty((3 * B * d,), dtype=torch.float32, device=dev) if dc.ctxq0 is not None else None))
+        # the news side's layer-0 tables (and the node table behind them) are read IN PLACE through the candidate ids when the
+        # encoder can (small news graphs: digat_encoder_fwd_grouped_cached's news_index): no gathered copies of 65 MB per batch
+        self.in_place = dc.news_hpq0 is not None and N <= 16 and d % 4 == 0 and d <= 1024 and in_place_tables
         self.sets = [bufs() for _ in range(nsets)]
         uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
         for s, e in self.batches:
@@ -282,7 +289,8 @@ class GroupedBatchPipeline:
             job(dc.user_graph.data_ptr(), b["user_graph"].data_ptr(), rowb(dc.user_graph), G, uniq_ptr)
             job(dc.user_category_mask.data_ptr(), b["cat_mask"].data_ptr(), rowb(dc.user_category_mask), G, uniq_ptr)
             job(dc.user_category_indices.data_ptr(), b["cat_idx"].data_ptr(), rowb(dc.user_category_indices), G, uniq_ptr)
-            job(dc.SA_news_representations.data_ptr(), b["sa"].data_ptr(), rowb(dc.SA_news_representations), n, cand_ptr)
+            if b["sa"] is not None:
+                job(dc.SA_news_representations.data_ptr(), b["sa"].data_ptr(), rowb(dc.SA_news_representations), n, cand_ptr)
             job(dc.news_graph.data_ptr(), b["news_graph"].data_ptr(), rowb(dc.news_graph), n, cand_ptr)
             job(dc.news_graph_mask.data_ptr(), b["news_mask"].data_ptr(), rowb(dc.news_graph_mask), n, cand_ptr)
             job(dc.c_n0.data_ptr(), b["c_n0"].data_ptr(), d * 4, n, cand_ptr)
@@ -310,15 +318,18 @@ class GroupedBatchPipeline:
         G, n, row_group = info
         b = self.sets[par]
         torch.cuda.current_stream(self.dev).wait_event(self.ready[par])
+        s0, e0 = self.batches[k]
+        sa = b["sa"][:n] if b["sa"] is not None else self.dc.SA_news_representations
         out = (b["user_rep"][:G], b["user_graph"][:G], b["cat_mask"][:G], b["cat_idx"][:G], row_group,
-               b["sa"][:n], b["news_graph"][:n], b["news_mask"][:n], b["c_n0"][:n])
-        N_, d_ = b["sa"].shape[1], b["sa"].shape[2]
+               sa, b["news_graph"][:n], b["news_mask"][:n], b["c_n0"][:n])
+        N_, d_ = self.dc.news_graph.shape[1], self.dc.news_embedding.shape[1]
         H_ = b["hist"].shape[1]
-        news_hpq = b["hpq"][:3 * n * N_ * d_].view(3, n, N_, d_) if b["hpq"] is not None else None
+        news_hpq = b["hpq"][:3 * n * N_ * d_].view(3, n, N_, d_) if b["hpq"] is not None else (self.dc.news_hpq0 if self.in_place else None)
+        news_index = self.dc.row_candidate[s0:e0] if self.in_place else None
         hist_hpq = b["hist_hpq"][:3 * G * H_ * d_].view(3, G, H_, d_) if b["hist_hpq"] is not None else None
         ctxq = b["ctxq"][:3 * n * d_].view(3, n, d_) if b["ctxq"] is not None else None
         if news_hpq is not None or hist_hpq is not None or ctxq is not None:
-            out = out + (news_hpq, hist_hpq, self.dc.topic_hpq0 if hist_hpq is not None else None, ctxq)
+            out = out + (news_hpq, hist_hpq, self.dc.topic_hpq0 if hist_hpq is not None else None, ctxq, news_index)
         return out
 
     def scored(self, k):
@@ -360,7 +371,7 @@ def batch_streams(device, count: int = 3):
 
 
 def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True,
-               streams: int = 3) -> torch.Tensor:
+               streams: int = 3, in_place_tables: bool = True) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
     tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``.  ``streams``:
     consecutive batches alternate over this many HIP streams (same kernels, same bits: see ``batch_streams``)."""
@@ -370,7 +381,8 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     batches = [(s, min(s + batch_size, end)) for s in range(start, end, batch_size)]
     lanes = batch_streams(dev, max(1, streams))
     with torch.no_grad():
-        pipe = GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes)) if grouped and batches else None
+        pipe = (GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes), in_place_tables=in_place_tables)
+                if grouped and batches else None)
         # the parameter block (split weights, folded queries) is (re)built on the first lane BEFORE the other lanes are
         # ordered after it: a rebuild inside the loop would run on one lane while the next batch reads it on the other
         enc = getattr(model, "graph_encoder", None)

@@ -278,12 +278,17 @@ int digat_user_project0(const digat_params* params, const float* X, float* hpq, 
  * the news alone.  digat_news_context_queries: c_n [M,d] -> out [3][M,d] (the encoder's own launch, row by row; folded path), kept
  * per news next to c_n0; the cached entry takes the batch's rows ctxq0 [3][B,d] (or NULL) and skips that launch.  Bit-identical. */
 int digat_news_context_queries(const digat_params* params, const float* c_n, float* out, int M, void* stream);
+/* news_index [B] int64 (or NULL) with news_rows: the per-news tables are read IN PLACE — news_graph_embeddings is then the table
+ * [news_rows, N, d] and news_hpq0 the table [3][news_rows, N, d], row b using their row news_index[b] — instead of the caller
+ * gathering the batch's rows (130 MB of copies per 1024-row batch at N = 10).  Needs news_graph_context, news_hpq0 and N <= 16
+ * (layer 0 of the news graph is then the only reader of the node table).  Bit-identical. */
 int digat_encoder_fwd_grouped_cached(const digat_params* params,
                                      const float* news_graph_embeddings, const uint8_t* news_graph, const uint8_t* news_graph_mask,
                                      const float* user_news_embedding_g, const uint8_t* user_graph_g,
                                      const uint8_t* user_category_mask_g, const int64_t* user_category_indices_g,
                                      const int32_t* row_group, const float* news_graph_context, const float* news_hpq0,
                                      const float* hist_hpq0, const float* topic_hpq0, const float* ctxq0,
+                                     const int64_t* news_index, int64_t news_rows,
                                      float* out_news, float* out_user, int B, int G, int N, int H,
                                      void* workspace, size_t workspace_bytes, void* stream);
 

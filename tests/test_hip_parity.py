@@ -742,6 +742,8 @@ def test_cached_news_projections_reproduce_the_in_batch_bits():
     saved_q, dc.ctxq0 = dc.ctxq0, None
     no_queries = util.score_rows(model, dc, 0, dc.rows, 512)
     assert torch.equal(with_tables, no_queries)
+    gathered = util.score_rows(model, dc, 0, dc.rows, 512, in_place_tables=False)     # the tables' rows copied per batch instead of
+    assert torch.equal(with_tables, gathered)                                          # read in place through the candidate ids
     dc.ctxq0 = saved_q
     dc.user_hpq0 = dc.topic_hpq0 = None
     news_only = util.score_rows(model, dc, 0, dc.rows, 512)
