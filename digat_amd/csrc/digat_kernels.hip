@@ -494,7 +494,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
                               const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
-                              const int64_t* news_index, int64_t news_rows) {
+                              const int64_t* news_index, int64_t news_rows, const float* c_n_src) {
+    // c_n_src: where the news context stands BEFORE layer 0 — c_n itself, or (depth >= 1, context given) the caller's c_n0, read
+    // in place by the two consumers that precede the first update instead of being copied into c_n first
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;       // the format every wsplit image of `p` was split in
@@ -509,7 +511,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     int rc;
     // the user-side queries + (optionally) the next user-graph K3, all from c_n
     auto from_c_n = [&](int next_layer, hipStream_t sq) -> int {
-        GemmArgs g = gemm_plain(c_n, d, p->user_news_fold_W, p->user_news_fold_b, kq_t, d, B, d, d, 0);
+        GemmArgs g = gemm_plain(next_layer == 0 ? c_n_src : c_n, d, p->user_news_fold_W, p->user_news_fold_b, kq_t, d, B, d, d, 0);
         g.w[1] = p->userAtt_fold_W; g.bias[1] = p->userAtt_fold_b; g.y[1] = kq_u;
         g.nsegs = 2;
         if (next_layer < L) {
@@ -536,7 +538,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (e) return e;
         return launch_pool(T2, (long)C1 * d, kq_user, cat_mask, addend, c_u, B, C1, d, sq);
     };
-    auto news_ctx = [&](const float* Xn_cur, hipStream_t sq) -> int {
+    auto news_ctx = [&](const float* Xn_cur, hipStream_t sq, bool first) -> int {
         const long ldx = (long)N * d;
         float* kq = kq_t;                          // free here: the previous user context has consumed it
         GemmArgs gq = gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0);
@@ -547,7 +549,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (e) return e;
         GemmArgs g = gemm_plain(Xn_cur, ldx, p->news_graph_W, p->news_graph_b, c_n, d, B, d, 2 * d, 0);
         g.k0 = d; g.a1 = glob; g.lda1 = d;
-        g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = c_n; g.lde2 = d;
+        g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = first ? c_n_src : c_n; g.lde2 = d;
         g.wsplit = (const unsigned short*)p->gate_wsplit; g.format = fmt; g.range_flag = rflag;
         return launch_gemm(g, sq);
     };
@@ -586,22 +588,19 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast);
+                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2);
         DIGAT_CHECK_LAUNCH();
         if (sparse_mode == DIGAT_XATTN_AUTO) {
             hipLaunchKernelGGL(sparse_decide_kernel, dim3(1), dim3(1024), 0, sq, (const int*)entries, B, U, g_sparse_per_node, flag);
             DIGAT_CHECK_LAUNCH();
             sparse_flag = flag;
         }
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt, off, B);
+        // node list and bucket list: both scans in one launch, both lists in one launch
+        const ScanPair sp{{cnt, cnt2}, {off, off2}};
+        hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(2), dim3(1024), 0, sq, sp, B);
         DIGAT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags1, (const int*)off, B, U, idx);
-        DIGAT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bucket_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, cat_mask, B, C1, flags2, cnt2);
-        DIGAT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, sq, (const int*)cnt2, off2, B);
-        DIGAT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(live_list_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, (const uint8_t*)flags2, (const int*)off2, B, C1, idx2);
+        const ListPair lp{{flags1, flags2}, {off, off2}, {U, C1}, {idx, idx2}};
+        hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, 2), dim3(256), 0, sq, lp, B);
         DIGAT_CHECK_LAUNCH();
         pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1; pend_hlast = hlast;
         return DIGAT_OK;
@@ -662,12 +661,14 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             // per news / per topic (digat_user_project0) and hands over the groups' history rows; the projection GEMM of the
             // groups becomes three assemblies [history rows | topic rows] (same kernel, same bits: rows are independent)
             float* dst[3] = {h0, P0, Q0};
+            UserNodes3 un3;
             for (int t = 0; t < 3; ++t) {
-                hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, sq,
-                                   (const float4*)(hist_hpq0 + (size_t)t * G * H * d), (const float4*)(topic_hpq0 + (size_t)t * C * d),
-                                   (float4*)dst[t], (long)G, H, C, d / 4, (const int*)nullptr);
-                DIGAT_CHECK_LAUNCH();
+                un3.hist[t] = (const float4*)(hist_hpq0 + (size_t)t * G * H * d);
+                un3.topic[t] = (const float4*)(topic_hpq0 + (size_t)t * C * d);
+                un3.dst[t] = (float4*)dst[t];
             }
+            hipLaunchKernelGGL(build_user_nodes3_kernel, dim3(blocks, 3), dim3(256), 0, sq, un3, (long)G, H, C, d / 4);
+            DIGAT_CHECK_LAUNCH();
             return DIGAT_OK;
         }
         GemmArgs gg = gemm_plain(Xg, d, lu.W, lu.bW, h0, d, G * U, d, d, 0);
@@ -832,7 +833,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
-        rc = news_ctx(xn_cur, sn);                 // c_n += ... (:196)
+        rc = news_ctx(xn_cur, sn, i == 0);         // c_n += ... (:196)
         if (rc) return rc;
         rc = from_c_n(i + 1, sn);                  // queries (+ next K3, into the other r_user buffer) from the UPDATED c_n
         if (rc) return rc;
@@ -940,7 +941,9 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         DIGAT_CHECK_LAUNCH();
     }
     // c_n: given (inference, :189) or computed (forward, :180); it lives in out_news from here on
-    if (c_n0) {
+    const bool c_n0_in_place = c_n0 && folded && L > 0;        // layer 0's news context update writes out_news from c_n0 directly
+    if (c_n0_in_place) {
+    } else if (c_n0) {
         if (hipMemcpyAsync(out_news, c_n0, (size_t)B * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return DIGAT_ERR_LAUNCH;
     } else {
@@ -951,7 +954,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
                                   xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g,
-                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows);
+                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
