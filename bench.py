@@ -832,6 +832,19 @@ def main():
                             "config": workload_config(W2, args, D)}
             del W2, r2
             torch.cuda.empty_cache()
+        # the DDP training step of the same shapes (trainer.py:71-105; `--mode train` times it alone): forward, backward, clip, Adam
+        try:
+            Wt = build_workload("mind-small-default", args, D, 4096, trainable=True)
+            rt = run_training(Wt, args, D, max(4, args.extra_steps), 2)
+            extra["mind-small-default/train-step"] = {"value": rt.rows_done / rt.elapsed, "unit": "rows/s",
+                                                      "ms_per_step": rt.elapsed / max(4, args.extra_steps) * 1e3,
+                                                      "rows_per_step": 320, "final_loss": rt.loss,
+                                                      "dtype": "f32 (bf16x6 matrix-core products, f32 accumulation)",
+                                                      "what": "64 behaviours x (1 + 4) candidates, graph encoder + trainable news table, dropout 0.2"}
+            del Wt, rt
+            torch.cuda.empty_cache()
+        except Exception as exc:          # the headline must not depend on the training leg
+            extra["mind-small-default/train-step"] = {"error": repr(exc)}
 
     e2e = None
     if D.world == 1 and args.e2e_impressions > 0 and args.workload == "auto" and args.extra_steps > 0:

@@ -47,8 +47,9 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert e2e["impressions"] == 1500 and e2e["seconds"] > 0 and e2e["rank_file_bytes"] > 0
     assert abs(sum(e2e["breakdown_s"].values()) - e2e["seconds"]) < 0.05 * e2e["seconds"] + 0.01
     ex = line["extra_workloads"]
-    assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16", "mind-small-default/bf16x6"}
-    assert all(v["value"] > 0 for v in ex.values())
+    assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16", "mind-small-default/bf16x6",
+                       "mind-small-default/train-step"}
+    assert all(v["value"] > 0 for v in ex.values()), ex
     assert "fp16x3" in line["config"]["projection"] and "two fp16 pieces" in line["config"]["projection_format"]
     assert ex["mind-small-default/bf16x6"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4
     assert ex["mind-small-default/pq-bf16"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4          # BASELINE configs[4], inference half
