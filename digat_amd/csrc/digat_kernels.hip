@@ -1046,10 +1046,7 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
     uint8_t* ci = cm + align_up((size_t)B * (C + 1), 256);
     {
         const GatherJobs jobs{{Au_g, cat_mask_g, (const uint8_t*)cat_idx_g}, {Au, cm, ci}, {(long)U * U, (long)(C + 1), (long)H * 8}};
-        const long total = (long)B * U * U;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, jobs, row_group, (long)B);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, st, jobs, row_group, (long)B);
         DIGAT_CHECK_LAUNCH();
     }
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
