@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — MIND-shaped dev impressions scored per second through the HIP DIGAT path.
 
-A step = one pass of the hot path over one batch of B=1024 (impression, candidate) rows of a synthetic
-MIND-shaped dev set: on-device gather of the batch from the HBM-resident corpus tables (util.py:65-67 of the
+A step = one pass of the hot path over one launch set of B=4096 (impression, candidate) rows — util.LAUNCH_ROWS: four of the
+reference's 1024-row dev batches (main.py:42) scored together; the 1024-row figure is extra_workloads[".../reference-batch-1024"]
+— of a synthetic MIND-shaped dev set: on-device gather of the batch from the HBM-resident corpus tables (util.py:65-67 of the
 reference) + ``Model.inference`` (DIGAT.inference, fp32) + dot-product logits.  Inputs are resident in HBM
 before the timed region.  The corpus has the real scale of the data set the workload names (MIND-small: 65 238 news,
 MIND-large: 161 013) and no batch is visited twice inside the timed region.
@@ -53,6 +54,7 @@ WORKLOADS = {
 }
 MIND_SMALL_DEV_ROWS = 2_740_000      # 73 152 impressions, ~2.74 M candidate rows
 MIND_SMALL_DEV_IMPRESSIONS = 73_152
+REFERENCE_BATCH = 1024               # the reference's dev batch: batch_size * 16 rows (main.py:42)
 
 
 def usable_cores() -> int:
@@ -77,10 +79,12 @@ def parse_args():
                          "dev run (title tokens -> rank file), which infer also appends at N = 1")
     ap.add_argument("--e2e-impressions", type=int, default=MIND_SMALL_DEV_IMPRESSIONS,
                     help="impressions of the end-to-end dev run (MIND-small dev: 73 152; 0 = skip it)")
-    ap.add_argument("--batch", type=int, default=1024, help="rows per step (reference: batch_size*16 = 1024, main.py:42)")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="rows per step = rows per launch set (util.LAUNCH_ROWS; the reference's dev batch is batch_size*16 = 1024 rows, "
+                         "main.py:42: sized for a 24 GB card, rows are independent)")
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS),
                     help="auto: mind-small-default on one GPU (BASELINE configs[1]), mind-large-default on several (configs[3])")
-    ap.add_argument("--impressions", type=int, default=20000, help="synthetic impressions per rank (~37 rows each)")
+    ap.add_argument("--impressions", type=int, default=40000, help="synthetic impressions per rank (~37 rows each)")
     ap.add_argument("--news", type=int, default=0, help="synthetic news corpus size (0 = the data set's real size)")
     ap.add_argument("--cpu-rows", type=int, default=1536, help="max rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU-baseline sample")
@@ -303,11 +307,11 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         for n in (3, 2, 3, 2, 3, 2):               # alternating rounds; the MEDIAN of each setting counts, and two batches in flight
             sc.join()                              # replace three only when clearly better (a coin-flip choice cost 3 % of a run)
             sc.nlanes = n
-            for _ in range(6):
+            for _ in range(max(3, 6 * 1024 // sc.B)):
                 sc.step()
             torch.cuda.synchronize()
             t_n = time.perf_counter()
-            for _ in range(40):
+            for _ in range(max(12, 40 * 1024 // sc.B)):
                 sc.step()
             torch.cuda.synchronize()
             trials[n].append(time.perf_counter() - t_n)
@@ -431,12 +435,15 @@ def rooflines(W, run, args):
         # HBM traffic comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) of this very
         # command; their per-launch means are kept under profiles/ and quoted here
         import glob
-        if W.name != "mind-small-default" or args.batch != 1024:
+        if W.name != "mind-small-default":
             return None
         for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")), reverse=True):
             try:
-                table = json.load(open(path))["kernels"]
+                doc = json.load(open(path))
+                table = doc["kernels"]
             except (OSError, ValueError, KeyError):
+                continue
+            if doc.get("rows_per_step", 1024) != args.batch:      # per-launch bytes belong to the launch size they were counted at
                 continue
             for name, v in table.items():
                 if symbols.get(kind, "\0") in name:
@@ -660,15 +667,15 @@ def run_e2e(args, D):
     # a short untimed pass first: code objects, allocator pools, clocks (the reference's 600 s include none of its own start-up either)
     small = util.DeviceCorpus.from_numpy(synthetic.slice_impressions(corpus, 0, 256), D.dev)
     small.title_text, small.title_mask = dc.title_text, dc.title_mask
-    util.compute_scores(model, small, args.batch, labels=corpus.row_label[:small.rows])
+    util.compute_scores(model, small, REFERENCE_BATCH, labels=corpus.row_label[:small.rows])
     del small
     t0 = clock()
     dc.news_embedding = util.cache_news_representations(model.news_encoder, dc.title_text, dc.title_mask, 8192)      # util.py:24-33
     dc.news_key = tuple((p.data_ptr(), p._version) for p in model.news_encoder.parameters())
     t1 = clock()
-    util.prepare_news_side(model.graph_encoder, dc, args.batch)                                                      # :34-44
+    util.prepare_news_side(model.graph_encoder, dc, REFERENCE_BATCH)                                                 # :34-44
     t2 = clock()
-    scores = util.score_rows(model, dc, 0, dc.rows, args.batch)                                                      # :51-69
+    scores = util.score_rows(model, dc, 0, dc.rows, REFERENCE_BATCH, launch_rows=args.batch)                         # :51-69
     t3 = clock()
     ranks, metrics = evaluate.device_ranks_and_metrics(scores, row_imp, corpus.row_label)                            # :70-80, evaluate.py
     t4 = clock()
@@ -684,7 +691,9 @@ def run_e2e(args, D):
             "breakdown_s": {"news_encoder_msa_65k_titles": round(t1 - t0, 4), "prepare_news_side": round(t2 - t1, 4),
                             "score_all_batches": round(t3 - t2, 4), "rank_and_metrics_on_device": round(t4 - t3, 4),
                             "rank_file_on_host": round(t5 - t4, 4)},
-            "batches": (corpus.rows + args.batch - 1) // args.batch, "rank_file_bytes": int(rank_file_bytes),
+            "reference_batches": (corpus.rows + REFERENCE_BATCH - 1) // REFERENCE_BATCH,
+            "launch_sets": len(util.launch_batches(0, corpus.rows, REFERENCE_BATCH, args.batch)), "rows_per_launch_set": args.batch,
+            "rank_file_bytes": int(rank_file_bytes),
             "metrics_random_clicks": [round(float(v), 4) for v in metrics], "fp16x3_range_overflow": overflow,
             "projection": model.graph_encoder.resolved_projection_mode(), "untimed_host_corpus_generation_s": round(gen_s, 1),
             "what": "util.compute_scores' flow from title tokens to the rank file at MIND-small dev scale, one GPU, synthetic data; the "
@@ -706,7 +715,7 @@ def workload_config(W, args, D):
             "user_side": "per row" if args.per_row_users else "once per impression (row_group index)",
             "user_graph_eq8": enc.resolved_xattn_mode("user") + " (chosen from the corpus: mean adjacency entries per node)",
             "news_graph_eq8": ("small-graph kernel (n <= 16)" if W.N <= 16 else enc.resolved_xattn_mode("news")),
-            "rows_per_step": args.batch, "N": W.N, "U": W.H + W.C, "d": W.d, "graph_depth": W.L,
+            "rows_per_step": args.batch, "reference_dev_batch_rows": REFERENCE_BATCH, "N": W.N, "U": W.H + W.C, "d": W.d, "graph_depth": W.L,
             "news_num": int(W.spec.news_num), "impressions_per_rank": int(W.spec.impressions), "rows_per_rank": int(W.corpus.rows),
             "device_table_bytes": W.table_bytes,
             "mean_candidates_per_impression": round(W.mean_cand, 3),
@@ -784,6 +793,18 @@ def main():
     if D.world == 1 and args.extra_steps > 0 and args.workload == "auto":
         # BASELINE configs[2] and the configs[3] shape, a few steps each, in the same invocation (same method, fewer steps)
         extra = {}
+        if args.batch != REFERENCE_BATCH:
+            # the headline's workload in the reference's own chunking: one launch set per 1024-row dev batch (main.py:42)
+            import copy
+            a1k = copy.copy(args)
+            a1k.batch = REFERENCE_BATCH
+            n1k = args.extra_steps * max(1, args.batch // REFERENCE_BATCH)
+            r1k = run_inference(W, a1k, D, n1k, 5, with_profile=False)
+            extra["mind-small-default/reference-batch-1024"] = {
+                "value": (r1k.rows_done / W.mean_cand) / r1k.elapsed, "unit": "impressions/s", "rows_per_s": r1k.rows_done / r1k.elapsed,
+                "ms_per_step": r1k.elapsed / n1k * 1e3, "rows_per_step": REFERENCE_BATCH, "steps": n1k,
+                "batches_in_flight": r1k.batches_in_flight,
+                "what": "util.score_rows(..., launch_rows=1024): every reference dev batch its own pass through the encoder"}
         if args.projection in ("auto", "bf16x6") and cpu_sample is not None:
             # BASELINE configs[4], inference half: the same workload with P', Q of Eq. 8 stored in bf16 (projection_mode
             # "pq-bf16"); metric drift on the rows of the CPU sample against the fp32 oracle

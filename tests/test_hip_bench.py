@@ -48,7 +48,11 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert abs(sum(e2e["breakdown_s"].values()) - e2e["seconds"]) < 0.05 * e2e["seconds"] + 0.01
     ex = line["extra_workloads"]
     assert set(ex) == {"mind-small-stress", "mind-large-default", "mind-small-default/pq-bf16", "mind-small-default/bf16x6",
-                       "mind-small-default/train-step"}
+                       "mind-small-default/train-step", "mind-small-default/reference-batch-1024"}
+    # a step is one launch set of util.LAUNCH_ROWS rows; the reference's own 1024-row chunking is reported next to it
+    assert line["config"]["rows_per_step"] == 4096 and line["config"]["reference_dev_batch_rows"] == 1024
+    assert ex["mind-small-default/reference-batch-1024"]["rows_per_step"] == 1024
+    assert e2e["rows_per_launch_set"] == 4096 and e2e["launch_sets"] <= e2e["reference_batches"]
     assert all(v["value"] > 0 for v in ex.values()), ex
     assert "fp16x3" in line["config"]["projection"] and "two fp16 pieces" in line["config"]["projection_format"]
     assert ex["mind-small-default/bf16x6"]["max_abs_metric_diff_vs_fp32_oracle"] <= 1e-4

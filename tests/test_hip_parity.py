@@ -340,6 +340,37 @@ def test_grouped_inference_is_bit_identical_to_per_row():
     assert torch.equal(a, b)
 
 
+def test_launch_set_size_does_not_move_the_scores():
+    """util.score_rows scores LAUNCH_ROWS = 4096 rows per pass through the encoder, four of the reference's 1024-row dev batches
+    (main.py:42): rows are independent, so the chunking may only move fp32 summation order (the [B,d] linears change kernels with
+    the row count).  Trained model, 74 k rows: 1024 / 4096 / 8192 rows per launch set and a ragged size against each other and
+    against the reference's own scores."""
+    from digat_amd import evaluate, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    from conftest import planted_devset
+    fx, corpus, state = planted_devset()
+    spec = corpus.spec
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                graph_depth=int(fx["depth"]), dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    assert util.LAUNCH_ROWS == 4096
+    got = {rows: util.score_rows(model, dc, 0, dc.rows, 1024, launch_rows=rows).cpu().numpy() for rows in (1024, None, 8192)}
+    got["ragged"] = util.score_rows(model, dc, 0, dc.rows, 600, launch_rows=2500).cpu().numpy()       # 2400-row sets, a 1712-row tail
+    ref = got[1024]
+    rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    for key, sc in got.items():
+        assert np.abs(sc - ref).max() <= 2e-5 * rms, key                       # fp32 noise; logits of rms ~10
+        m = evaluate.scoring(corpus.row_label, evaluate.impression_ranks(sc, corpus.row_impression), corpus.row_impression)
+        np.testing.assert_allclose(m, fx["metrics"], rtol=0, atol=1e-4, err_msg=str(key))
+        np.testing.assert_allclose(sc, fx["scores"], rtol=1e-4, atol=2e-4, err_msg=str(key))
+    assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024), torch.from_numpy(got[None]).to(_dev()))    # and repeatable
+
+
 @pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18), (3, 2, 1, 17)],
                          ids=["default", "stress-N65-L7", "large-N26", "depth1"])
 def test_side_stream_schedule_is_bit_identical_to_single_stream(neighbors, hops, L, cats):

@@ -120,3 +120,17 @@ def test_rank_file_bytes_equal_the_joined_rank_lines():
             imp, ranks = np.array([0, 0, 123456]), np.array([2, 1, 1])
         assert evaluate.rank_file_bytes(ranks, imp) == "\n".join(evaluate.rank_lines(ranks, imp)).encode()
     assert evaluate.rank_file_bytes(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)) == b""
+
+
+def test_launch_sets_are_whole_batches_covering_the_range():
+    """util.launch_batches: the row ranges one pass through the encoder takes — whole multiples of the caller's dev batch."""
+    from digat_amd import util
+    assert util.launch_batches(0, 10000, 1024) == [(0, 4096), (4096, 8192), (8192, 10000)]          # LAUNCH_ROWS = 4096
+    assert util.launch_batches(5, 3000, 1024, 1024) == [(5, 1029), (1029, 2053), (2053, 3000)]      # the reference's own chunking
+    assert util.launch_batches(0, 5000, 600, 2500) == [(0, 2400), (2400, 4800), (4800, 5000)]       # rounded down to whole batches
+    assert util.launch_batches(0, 5000, 8192) == [(0, 5000)]                                        # never below one batch
+    assert util.launch_batches(7, 7, 1024) == []
+    for start, end, b, rows in [(0, 99999, 1024, None), (3, 4099, 64, 1000), (0, 1, 1, 1)]:
+        sets = util.launch_batches(start, end, b, rows)
+        assert sets[0][0] == start and sets[-1][1] == end and all(a[1] == c[0] for a, c in zip(sets, sets[1:]))
+        assert all((e - s) % b == 0 for s, e in sets[:-1])
