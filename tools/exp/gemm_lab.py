@@ -21,8 +21,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     X = torch.randn(M, d, device=dev) * 0.5
     out = torch.empty(3, M, d, device=dev)
     Lb = _lib.lib()
+    Nn = int(os.environ.get("LAB_N", "1200"))              # LAB_N=400: one [400,400] linear on one-strip tiles (featureAffine's launch)
+    if Nn != 1200:
+        Wl = torch.randn(Nn, d, device=dev) * 0.05
+        bl = torch.randn(Nn, device=dev) * 0.05
+        img = torch.empty(Lb.digat_split_weights_bytes(Nn, d), dtype=torch.uint8, device=dev)
+        _lib.check(Lb.digat_split_weights(Wl.data_ptr(), Nn, d, img.data_ptr(), fmt, _lib.stream_ptr()), "split")
+        out = torch.empty(1, M, Nn, device=dev)
     def run():
-        _lib.check(Lb.digat_user_project0(P, X.data_ptr(), out.data_ptr(), M, _lib.stream_ptr()), "project0")
+        if Nn != 1200:
+            _lib.check(Lb.digat_linear_f32x3(X.data_ptr(), d, Wl.data_ptr(), bl.data_ptr(), out.data_ptr(), Nn, M, Nn, d, img.data_ptr(), fmt,
+                                             _lib.stream_ptr()), "linear")
+        else:
+            _lib.check(Lb.digat_user_project0(P, X.data_ptr(), out.data_ptr(), M, _lib.stream_ptr()), "project0")
     for _ in range(20): run()
     torch.cuda.synchronize()
     has_t = hasattr(Lb, "digat_debug_gemm_timers")
@@ -36,10 +47,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-    ref = (X.double() @ enc.user_graph_attention_W[0].weight.double().t() + enc.user_graph_attention_W[0].bias.double())
+    ref = (X.double() @ enc.user_graph_attention_W[0].weight.double().t() + enc.user_graph_attention_W[0].bias.double()) if Nn == 1200 \
+        else (X.double() @ Wl.double().t() + bl.double())
     err = float((out[0].double() - ref).abs().max())
-    fl = 2.0 * M * 1200 * 400
-    msg = f"{os.path.basename(_lib.LIB_PATH):28s} fmt={fmt} M={M}: median {sorted(ts)[2]:7.1f} us  best {min(ts):7.1f} us  {fl / min(ts) / 1e6:6.1f} TF fp32-eq  max err {err:.2e}"
+    fl = 2.0 * M * Nn * 400
+    msg = f"{os.path.basename(_lib.LIB_PATH):28s} fmt={fmt} M={M} N={Nn}: median {sorted(ts)[2]:7.1f} us  best {min(ts):7.1f} us  {fl / min(ts) / 1e6:6.1f} TF fp32-eq  max err {err:.2e}"
     if has_t:
         Lb.digat_debug_gemm_timers(o); v = list(o); w = max(v[6], 1); st = max(v[3], 1)
         msg += (f"\n    per sampled wave: total {v[7]/w:9.0f} ticks; prologue+loop {(v[7]-v[5])/w:9.0f}; epilogue {v[5]/w:8.0f}; per step: wait {v[0]/st:7.1f} "
