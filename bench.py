@@ -206,6 +206,8 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
         model.eval()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if hasattr(model.graph_encoder, "pass_rows"):
+            model.graph_encoder.pass_rows = args.batch
         util.prepare_news_side(model.graph_encoder, dc, args.batch)     # SA gather + c_n0 + layer-0 tables (setup, untimed)
         torch.cuda.synchronize()
         W.setup_ms = (time.perf_counter() - t0) * 1e3
@@ -233,6 +235,13 @@ class Scorer:
         self.lane_scores = [torch.empty(self.B, dtype=torch.float32, device=D.dev) for _ in self.lanes]
         self.k, self.base, self.pipe, self.order = 0, 0, None, None
         self.kept = [] if keep_scores else None
+        enc = W.model.graph_encoder
+        if hasattr(enc, "pass_rows"):
+            # rows per pass name the kernel of the [B,d] linears (util.score_rows does the same); per-news tables made under the
+            # other name are rebuilt, untimed
+            enc.pass_rows = args.batch
+            if W.dc.weights_key is not None and W.dc.weights_key != util.weights_key(enc, W.dc):
+                util.prepare_news_side(enc, W.dc, args.batch)
         with torch.cuda.stream(self.lanes[0]):
             W.model.graph_encoder._params()        # split weights / folded queries built before the lanes fork (util.score_rows)
 
@@ -399,9 +408,16 @@ def run_training(W, args, D: Dist, steps, warmup):
         idx = (np.arange(64) + 64 * (k % nb)) % len(ts)
         k += 1
         return tr.train_step(idx)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
-        step()
+    # pre-warm (clocks, allocator, code objects): by the clock on one rank; with more ranks every step is a collective (DDP's
+    # gradient all-reduce), so every rank must take the SAME number of them — a per-rank clock would leave one rank waiting forever
+    if D.world == 1:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.5:
+            step()
+            torch.cuda.synchronize()
+    else:
+        for _ in range(24):
+            step()
         torch.cuda.synchronize()
     for _ in range(warmup):
         step()

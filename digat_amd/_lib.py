@@ -19,6 +19,7 @@ DIGAT_MAX_DEPTH = 16
 DIGAT_MAX_NODES = 128
 GEMM_BF16X6, GEMM_F16X3 = 0, 1          # operand format of a split weight image (include/digat_hip.h)
 PARAMS_GEMM_F16X3 = 64                  # digat_params.flags: the block's wsplit images are GEMM_F16X3
+PARAMS_BD_TILED = 128                   # digat_params.flags: the [B,d] linears run on the tiled kernel at every row count
 
 _f = C.c_void_p  # every device pointer crosses as void*
 

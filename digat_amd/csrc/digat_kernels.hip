@@ -501,6 +501,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     const int d = p->d, C = p->category_num, L = p->depth, U = H + C, C1 = C + 1;
     const int fmt = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0;       // the format every wsplit image of `p` was split in
     unsigned* const rflag = fmt ? (unsigned*)p->range_flag : nullptr;
+    // the kernel of the [B,d] linears is named by the caller, not chosen from B: a row's bits must not depend on the batch it sits in
+    // (nor on whether its context queries come from the per-news table)
+    const int bd_disp = (p->flags & DIGAT_PARAMS_BD_TILED) ? (1 << 30) : 1;
     const size_t s2 = align_up((size_t)B * C1 * d * 4, 256);
     float* T = (float*)cws;                       // [B,C1,d] pooled topics
     float* T2 = (float*)((char*)cws + s2);        // after featureAffine
@@ -519,6 +522,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             g.nsegs = 3;
         }
         g.wsplit = (const unsigned short*)p->ctx_wsplit[next_layer]; g.format = fmt; g.range_flag = rflag;   // NULL: fp32 MFMA
+        g.m_dispatch = bd_disp;
         return launch_gemm(g, sq);
     };
     // `live` (layers' outputs): the rows of dead nodes were never written — the topic pooling takes them as zero
@@ -543,6 +547,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         float* kq = kq_t;                          // free here: the previous user context has consumed it
         GemmArgs gq = gemm_plain(Xn_cur, ldx, p->cand_fold_W, p->cand_fold_b, kq, d, B, d, d, 0);
         gq.wsplit = (const unsigned short*)p->cand_fold_wsplit; gq.format = fmt; gq.range_flag = rflag;
+        gq.m_dispatch = bd_disp;
         int e = launch_gemm(gq, sq);
         if (e) return e;
         e = launch_pool(Xn_cur, ldx, kq, Mn, nullptr, glob, B, N, d, sq);
@@ -551,6 +556,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         g.k0 = d; g.a1 = glob; g.lda1 = d;
         g.epi = EPI_GATE; g.e0 = Xn_cur; g.lde0 = ldx; g.e1 = glob; g.lde1 = d; g.e2 = first ? c_n_src : c_n; g.lde2 = d;
         g.wsplit = (const unsigned short*)p->gate_wsplit; g.format = fmt; g.range_flag = rflag;
+        g.m_dispatch = 1;          // two-operand input: the split-image [B,d] kernel at every row count (the tiled one does not take it)
         return launch_gemm(g, sq);
     };
 
@@ -810,6 +816,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         {
             GemmArgs g3 = gemm_plain(c_u, d, ln.F3, ln.b3, r_news, d, B, d, d, 0);              // K3 of the news graph
             g3.wsplit = (const unsigned short*)ln.f3_wsplit; g3.format = fmt; g3.range_flag = rflag;
+            g3.m_dispatch = bd_disp;
             rc = launch_gemm(g3, sn);
         }
         if (rc) return rc;
@@ -1088,7 +1095,7 @@ int digat_news_context_queries(const digat_params* p, const float* c_n, float* o
     if (L > 0) { g.w[2] = p->user[0].F3; g.bias[2] = p->user[0].b3; g.y[2] = out + 2 * md; g.nsegs = 3; }
     g.wsplit = (const unsigned short*)p->ctx_wsplit[0];
     g.format = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0; g.range_flag = g.format ? (unsigned*)p->range_flag : nullptr;
-    g.m_dispatch = 1;                      // the [B,d] kernel whatever M is: the same bits as inside a batch
+    g.m_dispatch = (p->flags & DIGAT_PARAMS_BD_TILED) ? (1 << 30) : 1;      // the kernel the encoder uses for this linear inside a batch: same bits
     return launch_gemm(g, (hipStream_t)stream);
 }
 

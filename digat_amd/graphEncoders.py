@@ -84,6 +84,10 @@ class DIGAT(GraphEncoder):
         self._range_flag = None            # device word raised by the fp16x3 GEMMs on out-of-range activations (range_flag())
         self.range_fallback = False        # set by util.compute_scores after such a run: "auto" then resolves to bf16x6
         self.corpus_activation_max = None  # max |news representation| of the corpus, set by util.prepare_news_side
+        # rows the driver passes through inference() per call (util.score_rows sets it to its launch-set size, util.LAUNCH_ROWS):
+        # it NAMES the kernel of the [B,d] linears (>= 2048: tiled split-operand, below: split-image; DIGAT_PARAMS_BD_TILED) —
+        # the row count of a call does not, so a row's bits do not depend on the batch it sits in
+        self.pass_rows = 4096
         # Eq. 8 of the user graph: "auto" (the device counts the adjacency entries of the batch and runs the sparse
         # edge-list kernel or the dense tile + MFMA pair), "dense", "sparse" (digat_params.flags, include/digat_hip.h)
         self.user_xattn_mode = "auto"
@@ -270,14 +274,15 @@ class DIGAT(GraphEncoder):
 
     def _flags(self) -> int:
         """digat_params.flags (include/digat_hip.h): Eq. 8 variant of the user graph (bits 0-1), DIGAT_PROJ_PQ_X3 (bit 2),
-        DIGAT_NEWS_XATTN_SPARSE (bit 3)."""
+        DIGAT_NEWS_XATTN_SPARSE (bit 3), ..., DIGAT_PARAMS_BD_TILED (bit 7: ``pass_rows``)."""
         pm = self.projection_mode
         return ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
                 | (4 if pm in ("bf16x6-pq3", "pq-bf16") else 0)
                 | (8 if self.resolved_xattn_mode("news") == "sparse" else 0)
                 | (16 if pm in ("pq-bf16", "pq-bf16-x1") else 0)         # DIGAT_PQ_BF16: P', Q of Eq. 8 stored in bf16
                 | (32 if pm == "pq-bf16-x1" else 0)                      # DIGAT_PQ_X1: ... and computed with one bf16 product
-                | (_lib.PARAMS_GEMM_F16X3 if self.gemm_format() == _lib.GEMM_F16X3 else 0))
+                | (_lib.PARAMS_GEMM_F16X3 if self.gemm_format() == _lib.GEMM_F16X3 else 0)
+                | (_lib.PARAMS_BD_TILED if self.pass_rows >= 2048 else 0))
 
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention

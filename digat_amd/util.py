@@ -160,7 +160,8 @@ def weights_key(encoder, dc: DeviceCorpus) -> tuple:
     params = tuple((p.data_ptr(), p._version) for p in encoder.parameters()) if hasattr(encoder, "parameters") else ()
     pm = encoder.resolved_projection_mode() if hasattr(encoder, "resolved_projection_mode") else getattr(encoder, "projection_mode", None)
     fmt = encoder.gemm_format() if hasattr(encoder, "gemm_format") else None
-    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt)
+    # ... and the kernel that computes the context-query table (the encoder's pass_rows names it: same bits as inside a pass)
+    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt, getattr(encoder, "pass_rows", 0) >= 2048)
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
@@ -386,6 +387,12 @@ def launch_batches(start: int, end: int, batch_size: int, launch_rows: Optional[
     return [(s, min(s + step, end)) for s in range(start, end, step)]
 
 
+def _pass_rows(batch_size: int, launch_rows: Optional[int] = None) -> int:
+    """Rows of a full launch set (what ``launch_batches`` steps by)."""
+    rows = LAUNCH_ROWS if launch_rows is None else launch_rows
+    return batch_size * max(1, rows // max(1, batch_size))
+
+
 def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True,
                streams: int = 3, in_place_tables: bool = True, launch_rows: Optional[int] = None) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
@@ -397,6 +404,13 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     scores = torch.empty(end - start, dtype=torch.float32, device=dev)
     grouped = grouped and hasattr(model, "inference_grouped")
     batches = launch_batches(start, end, batch_size, launch_rows)
+    enc = getattr(model, "graph_encoder", None)
+    if hasattr(enc, "pass_rows") and batches:
+        # the launch-set size names the kernel of the [B,d] linears for the whole run (tail set included); per-news tables made
+        # under the other name are rebuilt (they hold the same linears' results)
+        enc.pass_rows = _pass_rows(batch_size, launch_rows)
+        if dc.weights_key is not None and dc.weights_key != weights_key(enc, dc):
+            prepare_news_side(enc, dc, batch_size)
     lanes = batch_streams(dev, max(1, streams))
     with torch.no_grad():
         pipe = (GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes), in_place_tables=in_place_tables)
@@ -460,6 +474,8 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
             dc.news_key = nk               # a new tensor: weights_key below changes and the per-news caches follow
     if score_fn is None and hasattr(model.graph_encoder, "range_overflowed"):
         model.graph_encoder.range_overflowed()                      # clear what earlier calls may have left in the flag
+    if score_fn is None and hasattr(model.graph_encoder, "pass_rows"):
+        model.graph_encoder.pass_rows = _pass_rows(batch_size)      # what score_rows will pass per call: names the [B,d] kernel
     if score_fn is None and (dc.c_n0 is None or dc.weights_key != weights_key(model.graph_encoder, dc)):
         prepare_news_side(model.graph_encoder, dc, batch_size)      # first use, or the weights moved on since (an optimizer
                                                                     # step, load_state_dict): the per-news caches are stale

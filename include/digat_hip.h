@@ -149,6 +149,11 @@ enum { DIGAT_PQ_BF16 = 16, DIGAT_PQ_X1 = 32 };
 /* digat_params.flags bit 6: every wsplit image of this parameter block (layers' [W|ffn1|ffn2], featureAffine) was split with
  * format DIGAT_GEMM_F16X3 (two scaled fp16 pieces, three products); clear = DIGAT_GEMM_BF16X6.  See digat_split_proj_weights. */
 enum { DIGAT_PARAMS_GEMM_F16X3 = 64 };
+/* digat_params.flags bit 7: which kernel runs the [B,d] linears of the folded inference path (context queries, candidate query, K3 of the
+ * news graph) and digat_news_context_queries' table — set: the tiled split-operand kernel (right for passes of >= 2 048 rows), clear:
+ * the split-image [B,d] kernel (right below that).  The CALLER names it, the row count does not choose: a row's bits then do not
+ * depend on the batch it sits in, nor on whether its queries were computed in the batch or read from the per-news table. */
+enum { DIGAT_PARAMS_BD_TILED = 128 };
 
 typedef struct digat_layer_params {
     const float *W, *bW;      /* {g}_graph_attention_W.i.{weight,bias}    */

@@ -23,7 +23,7 @@ def _last_json_line(out):
 def test_bench_single_gpu_prints_the_contract_line():
     cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "600", "--news", "2048",
            "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2", "--e2e-impressions", "1500"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert REQUIRED <= set(line) and "cpu_baseline" in line
@@ -66,7 +66,7 @@ def test_bench_two_ranks_sum_their_rows():
     env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "600", "--news", "2048"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert REQUIRED <= set(line)
@@ -83,7 +83,7 @@ def test_bench_two_gpus_starts_its_own_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(DIGAT_BENCH_TEST_SHARED_GPU="1")
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--impressions", "600", "--news", "2048"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert REQUIRED <= set(line)
@@ -98,7 +98,7 @@ def test_bench_train_mode_two_ranks_ddp():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29733", "bench.py", "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1",
            "--impressions", "400", "--news", "2048"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     assert line["n_gpus"] == 2 and line["unit"] == "rows/s" and line["value"] > 0 and "ddp2" in line["config"]["parallelism"]
@@ -111,7 +111,7 @@ def test_bench_train_mode_with_the_msa_news_encoder():
     backward end to end."""
     cmd = [sys.executable, "bench.py", "--mode", "train", "--train-news-encoder", "msa", "--steps", "3", "--warmup", "1",
            "--impressions", "400", "--news", "2048"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _last_json_line(res.stdout)
     import math

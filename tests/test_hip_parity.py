@@ -369,6 +369,13 @@ def test_launch_set_size_does_not_move_the_scores():
         np.testing.assert_allclose(m, fx["metrics"], rtol=0, atol=1e-4, err_msg=str(key))
         np.testing.assert_allclose(sc, fx["scores"], rtol=1e-4, atol=2e-4, err_msg=str(key))
     assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024), torch.from_numpy(got[None]).to(_dev()))    # and repeatable
+    # sets of 2048 rows or more share every kernel (the encoder is told the pass size, DIGAT_PARAMS_BD_TILED; the row count of
+    # a call — the ragged tail included — chooses nothing): bit-identical scores
+    assert np.array_equal(got[None], got[8192]) and np.array_equal(got[None], got["ragged"])
+    # ... and so do sets below that among themselves, tail sets included
+    small = util.score_rows(model, dc, 0, 9000, 1024, launch_rows=1024).cpu().numpy()
+    assert np.array_equal(small, util.score_rows(model, dc, 0, 9000, 512, launch_rows=1536).cpu().numpy())
+    assert np.array_equal(small, got[1024][:9000])
 
 
 @pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18), (3, 2, 1, 17)],
