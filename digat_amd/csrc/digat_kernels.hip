@@ -455,7 +455,11 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
 static int g_sparse_per_node = getenv("DIGAT_SPARSE_PER_NODE") ? atoi(getenv("DIGAT_SPARSE_PER_NODE")) : 12;
-static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") && atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1;
+// 0 = never, 1 = always, 2 = by pass size (default): below 2 048 rows — there the news kernels are a few waves of workgroups each;
+// from 2 048 rows up every kernel fills the chip by itself and the second stream only makes launches share it (4 096 rows,
+// three passes in flight: 3.21 vs 3.28 ms per pass; stress 16.4 vs 16.8, MIND-large shape 4.52 vs 4.65).  DIGAT_SINGLE_STREAM=1 / 0
+// forces never / always.
+static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") ? (atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1) : 2;
 // layer 0 of the user graph on the live nodes only (A/B switch for measurements; DIGAT_L0_LIVE=0: every node at layer 0)
 static int g_l0_live_on = getenv("DIGAT_L0_LIVE") ? atoi(getenv("DIGAT_L0_LIVE")) : 1;
 // 0 (default): the wave-per-centre sparse kernel; 1: the LDS-staged kernels of digat_staged.inc (compulsory HBM traffic, measured
@@ -622,7 +626,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
         hist_last = pend_hlast;
     };
-    SideStream* side = side_stream(st);
+    SideStream* side = (g_side_stream_on == 2 && B >= 2048) ? nullptr : side_stream(st);
     // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
     // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
     // layer i+1's under the pooling of user context i — instead of waiting for c_u.
@@ -1013,9 +1017,9 @@ int digat_set_staged_xattn(int mode) {
     return prev;
 }
 
-int digat_set_side_stream(int enabled) {
+int digat_set_side_stream(int enabled) {      // 0 = never, 1 = always, 2 = by pass size (the default); returns the previous setting
     const int prev = g_side_stream_on;
-    g_side_stream_on = enabled ? 1 : 0;
+    g_side_stream_on = enabled == 2 ? 2 : (enabled ? 1 : 0);
     return prev;
 }
 

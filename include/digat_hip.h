@@ -227,8 +227,9 @@ int digat_encoder_fwd(const digat_params* params,
 
 /* With the folded-query fields set, digat_encoder_fwd / _grouped run the news-graph kernels of a layer (small:
  * N nodes, [B,d] linears) on an internal side stream under the user graph's Eq. 8 and join before the user
- * context is pooled (two events per layer; capturable).  0 keeps every launch on the caller's stream (also: env DIGAT_SINGLE_STREAM=1).  Returns
- * the previous setting.  Results do not depend on it. */
+ * context is pooled (two events per layer; capturable) — by default for passes below 2 048 rows (2: from there up every kernel fills
+ * the chip by itself and a second stream only makes launches share it).  1 = always, 0 = every launch on the caller's stream
+ * (env DIGAT_SINGLE_STREAM=0 / 1 force the same).  Returns the previous setting.  Results do not depend on it. */
 int digat_set_side_stream(int enabled);
 
 /* User-graph nodes that cannot reach the encoder's outputs — no edge to another node, and pooled only into a
