@@ -375,7 +375,8 @@ def batch_streams(device, count: int = 3):
 # [B, n, n, d] activations allow; here rows are independent and nothing of that size exists, so consecutive dev batches are
 # scored together: 4 096 rows per launch set fill the chip's 256 CUs better (the [B,d] linears, poolings and the news graph
 # are 1-4 waves of workgroups at 1 024 rows).  Measured per 1 024 rows, three launch sets in flight: 1 024: 0.93 ms, 2 048:
-# 0.92, 4 096: 0.85, 8 192: 0.84 — scores equal to the last fp32 bits or so ([B,d] linears change kernels with the row count).
+# 0.92, 4 096: 0.80, 8 192: 0.80 — scores equal to the last fp32 bits or so (the [B,d] linears run on the tiled kernel from 2 048
+# rows per pass up: DIGAT.pass_rows).
 LAUNCH_ROWS = 4096
 
 
