@@ -814,7 +814,7 @@ def main():
             import copy
             a1k = copy.copy(args)
             a1k.batch = REFERENCE_BATCH
-            n1k = args.extra_steps * max(1, args.batch // REFERENCE_BATCH)
+            n1k = args.extra_steps * 10                    # 120 short steps by default: a 48-step sample scattered by 8 % run to run
             r1k = run_inference(W, a1k, D, n1k, 5, with_profile=False)
             extra["mind-small-default/reference-batch-1024"] = {
                 "value": (r1k.rows_done / W.mean_cand) / r1k.elapsed, "unit": "impressions/s", "rows_per_s": r1k.rows_done / r1k.elapsed,
