@@ -378,6 +378,44 @@ def test_launch_set_size_does_not_move_the_scores():
     assert np.array_equal(small, got[1024][:9000])
 
 
+def test_big_passes_edge_cases():
+    """4096-row passes on corpora that leave the grouped fast path or its defaults: impressions of one or two candidates (more
+    groups than a quarter of the rows: the pipeline hands such sets to the per-row entry), a single lane (util.score_rows then
+    keeps the library's side stream on), the pass size changed between calls (per-news tables rebuilt under the other [B,d]
+    kernel), and a run that is one ragged set.  Everything against the per-row path at the same pass size, bit for bit."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    L = 3
+    for mean_c, max_c, imps in ((1.6, 3, 3000), (30.0, 80, 300)):
+        spec = synthetic.SynthSpec(news_num=2048, sag_neighbors=3, sag_hops=2, impressions=imps, mean_candidates=mean_c,
+                                   max_candidates=max_c, seed=211)
+        corpus = synthetic.make_corpus(spec)
+        state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=212, bias_std=0.05)
+        cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                    max_history_num=spec.max_history_num, category_num=spec.category_num,
+                                    graph_depth=L, dropout_rate=0.2)
+        model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+        model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        model = model.to(_dev()).eval()
+        dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+        assert dc.rows > 4096 + 300
+        util.prepare_news_side(model.graph_encoder, dc, 1024)
+        ref = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)                 # per-row entry, 4096-row passes
+        assert model.graph_encoder.pass_rows == 4096
+        assert torch.isfinite(ref).all()
+        assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024), ref)             # grouped (or handed to per-row: tiny groups)
+        assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024, streams=1), ref)  # one lane, side stream on
+        assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024, streams=2), ref)
+        key_big = dc.weights_key
+        small = util.score_rows(model, dc, 0, dc.rows, 1024, launch_rows=1024)            # the other [B,d] kernel: tables rebuilt
+        assert model.graph_encoder.pass_rows == 1024 and dc.weights_key != key_big
+        assert torch.equal(small, util.score_rows(model, dc, 0, dc.rows, 1024, launch_rows=1024, grouped=False))
+        rms = float(ref.double().pow(2).mean().sqrt())
+        assert float((small - ref).abs().max()) <= 2e-5 * rms
+        assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024), ref)             # and back
+        assert torch.equal(util.score_rows(model, dc, 100, 100 + 777, 1024), ref[100:100 + 777])    # one ragged set, offset start
+
+
 @pytest.mark.parametrize("neighbors,hops,L,cats", [(3, 2, 3, 17), (8, 2, 7, 17), (5, 2, 3, 18), (3, 2, 1, 17)],
                          ids=["default", "stress-N65-L7", "large-N26", "depth1"])
 def test_side_stream_schedule_is_bit_identical_to_single_stream(neighbors, hops, L, cats):
