@@ -96,9 +96,9 @@ def parse_args():
     ap.add_argument("--train-news-encoder", default="table", choices=["table", "msa"],
                     help="--mode train: 'table' = news representations from a trainable table (graph-encoder step only); 'msa' = the "
                          "reference's full step, MSA news encoder on the titles of 64 x (5 x N + H) news per step")
-    ap.add_argument("--projection", default="auto", choices=["auto", "bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1", "fp16x3"],
+    ap.add_argument("--projection", default="auto", choices=["auto", "bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1", "pq-fp8", "fp16x3"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
-                         "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one)")
+                         "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one); pq-fp8: stored as block-scaled e4m3")
     return ap.parse_args()
 
 
@@ -474,7 +474,7 @@ def rooflines(W, run, args):
             # the projections run as 6 bf16 MFMA products per fp32 product (exact 3-way operand split; "bf16x6-pq3": 6 for h,
             # 3 for P and Q = 4 on average): price the EXECUTED bf16 flops against the dense bf16 peak, and quote the
             # fp32-equivalent rate
-            nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-bf16-x1": 8.0 / 3.0, "fp16x3": 3.0}[pmode]
+            nprod = {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-fp8": 4.0, "pq-bf16-x1": 8.0 / 3.0, "fp16x3": 3.0}[pmode]
             if hasattr(enc, "gemm_format") and enc.gemm_format() == 1:          # two fp16 pieces: three products whatever the mode
                 nprod = 3.0
             return {"kernel": "proj (gemm_bf16x6s_kernel)", "bound": "mfma", "achieved": nprod * rate / 1e12,
@@ -482,7 +482,7 @@ def rooflines(W, run, args):
                     "traffic": pmc_traffic(kind),
                     "mfma_dtype": ("fp16 (2-way split of f32, f32 accumulate; products per fp32 product: %s)" if pmode == "fp16x3" else
                                    "bf16 (3-way split of f32, f32 accumulate; products per fp32 product: %s)")
-                                  % {"bf16x6": "6", "bf16x6-pq3": "6 for h, 3 for P and Q", "pq-bf16": "6 for h, 3 for P and Q",
+                                  % {"bf16x6": "6", "bf16x6-pq3": "6 for h, 3 for P and Q", "pq-bf16": "6 for h, 3 for P and Q", "pq-fp8": "6 for h, 3 for P and Q",
                                      "pq-bf16-x1": "6 for h, 1 for P and Q (user graph, layers >= 1)",
                                      "fp16x3": "3 (two fp16 pieces per operand)"}[pmode],
                     # the same launches priced by their ALGORITHMIC flops (2 M N K of the fp32 product) against the fp32 matrix-core
@@ -911,7 +911,8 @@ def main():
         "vs_baseline": None,
         # fp32 data and fp32-grade arithmetic; how the >= 2048-row GEMMs form their fp32 products on the matrix cores is
         # config.projection / config.projection_format
-        "dtype": "f32" if not args.projection.startswith("pq-bf16") else "f32 with P', Q of the user graph's Eq. 8 in bf16 (configs[4])",
+        "dtype": ("f32 with P', Q of the user graph's Eq. 8 as block-scaled e4m3 (configs[4])" if args.projection == "pq-fp8" else
+                  "f32" if not args.projection.startswith("pq-bf16") else "f32 with P', Q of the user graph's Eq. 8 in bf16 (configs[4])"),
         "data": "synthetic",
         "valid": bool(matched or auc_match is None),
         "config": workload_config(W, args, D),

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "digat_xattn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_xattn_fwd": (C.c_int, [_f] * 12 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_xattn_fwd_mode": (C.c_int, [_f] * 11 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
+    "digat_xattn_fwd_lowprec": (C.c_int, [_f] * 11 + [C.c_int, _f] + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_xattn_pairwise_fwd": (C.c_int, [_f] * 8 + [C.c_int] * 3 + [_f]),
     "digat_news_ctx_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_fwd": (C.c_int, [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),

@@ -187,16 +187,22 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     // DIGAT_PQ_BF16 (pq_mode & 1): P' and Q stored in bf16, read by the wave-per-centre sparse kernel; & 2: one product for them
     const bool pq16 = (pq_mode & 1) && gemm_is_bf16x6(g) && sparse_mode == DIGAT_XATTN_SPARSE && !alpha_out && !plan && n > 16 &&
                       d / 4 <= 256 && d % 8 == 0 && (long)B * n >= 2048;
+    // DIGAT_PQ_FP8 (pq_mode & 4): P' and Q stored as block-scaled e4m3 rows (one fp32 scale per 80-channel strip), same reader
+    const bool pq8 = (pq_mode & 4) && !(pq_mode & 1) && gemm_is_bf16x6(g) && sparse_mode == DIGAT_XATTN_SPARSE && !alpha_out && !plan && n > 16 &&
+                     d / 4 <= 256 && d % 80 == 0 && (long)B * n >= 2048;
+    const long ld8 = (long)align_up((size_t)d + 4 * (size_t)(d / 80), 64);      // [d codes | d / 80 scales | pad]: whole 64-byte lines
     if (pq16) { g.bf16_segs = 6; if (pq_mode & 2) g.x1_segs = 6; }
+    if (pq8) { g.fp8_segs = 6; g.ldy8 = ld8; if (pq_mode & 2) g.x1_segs = 6; }
     const bool listed = rowidx && gemm_is_bf16x6(g);
     if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
     const int* skip_if = nullptr;
     if (sparse_mode != DIGAT_XATTN_DENSE && !alpha_out && n > 16 && d / 4 <= 256) {      // see xattn_sparse_kernel
-        const SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
-                            sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
-                            listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq16 ? 1 : 0, plan ? 0 : centre_limit};
+        SparseArgs sg{P, Q, h, X, a, A, out, nullptr, nullptr, listed ? live : nullptr,
+                      sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
+                      listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq8 ? 2 : (pq16 ? 1 : 0), plan ? 0 : centre_limit};
+        sg.ld8 = pq8 ? ld8 : 0;
         // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
         const int rcs = plan ? launch_staged(sg, *plan, listed && live ? 1 : 0, plan_slot, st) : launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
@@ -240,6 +246,24 @@ int digat_xattn_fwd_mode(const float* X, const uint8_t* A, const float* ctx,
     const int rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
     if (rc) return rc;
     return xattn_core(X, A, r, W, bW, F1, F2, a, out, nullptr, B, n, d, workspace, st, nullptr, nullptr, nullptr, nullptr, mode);
+}
+
+int digat_xattn_fwd_lowprec(const float* X, const uint8_t* A, const float* ctx,
+                            const float* W, const float* bW, const float* F1, const float* F2,
+                            const float* F3, const float* b3, const float* a, const void* wsplit, int format,
+                            float* out, int B, int n, int d, int pq,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (pq < 0 || pq > 2 || (format != 0 && format != 1)) return DIGAT_ERR_ARG;
+    if (!X || !A || !ctx || !W || !F1 || !F2 || !F3 || !a || !wsplit || !out || !workspace) return DIGAT_ERR_ARG;
+    if (B < 0 || n <= 0 || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 80 || d > 1024 || n <= 16 || n > DIGAT_MAX_NODES || (long)B * n < 2048) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_xattn_workspace_bytes(B, n, d)) return DIGAT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* r = (float*)((char*)workspace + align_up((size_t)3 * B * n * d * 4, 256));
+    const int rc = launch_gemm(gemm_plain(ctx, d, F3, b3, r, d, B, d, d, 0), st);
+    if (rc) return rc;
+    return xattn_core(X, A, r, W, bW, F1, F2, a, out, nullptr, B, n, d, workspace, st, wsplit, nullptr, nullptr, nullptr, DIGAT_XATTN_SPARSE,
+                      nullptr, 0, nullptr, 0, pq == 1 ? 1 : (pq == 2 ? 4 : 0), 0, format, nullptr);
 }
 
 // ---- bf16x6 weight preparation + a directly callable linear (tests, micro-benchmarks) --------------
@@ -809,7 +833,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
                             lv_on ? rowidx : nullptr, lv_on ? nrows_dev : nullptr, lv_on ? live_flags : nullptr, sparse_mode,
                             sparse_flag, pq_x3, use_staged ? &plan : nullptr, i,
-                            i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) : 0,
+                            i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) | ((p->flags & DIGAT_PQ_FP8) ? 4 : 0) : 0,
                             // after the last layer only the history rows are read (the user context's topic pooling, :124):
                             // the topic nodes' own Eq. 8 is not computed there (wave-per-centre sparse kernel)
                             (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0, fmt, rflag);
@@ -840,7 +864,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             nullptr, nullptr, nullptr, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
                             nullptr, pq_x3, nullptr, 0,
                             // the news graph's P' always carries K3 from the GEMM epilogue: bf16 storage applies at every layer
-                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0), 0, fmt, rflag);
+                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) | ((p->flags & DIGAT_PQ_FP8) ? 4 : 0), 0, fmt, rflag);
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;

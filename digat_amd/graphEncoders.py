@@ -76,6 +76,8 @@ class DIGAT(GraphEncoder):
         # for h, three of the six products for P and Q (they only feed the score: DIGAT_PROJ_PQ_X3), "fp32" = v_mfma_f32_16x16x4_f32;
         # BASELINE configs[4]: "pq-bf16" = pq3 + P', Q of the user graph's layers >= 1 STORED in bf16 (DIGAT_PQ_BF16; the
         # reference's quantised K3 + K1 + K2, README.md:62-66), "pq-bf16-x1" = the same with one bf16 product for P and Q;
+        # "pq-fp8" = the same launches with P', Q stored as block-scaled OCP e4m3 (DIGAT_PQ_FP8: one fp32 scale per row and
+        # 80-channel strip; the fp8 half of configs[4]);
         # "fp16x3" = every operand as two fp16 pieces, three products (digat_set_gemm_format(1): 0.7x the GEMM time, error at or
         # below an fp32 fma chain's against fp64 for |w| < 63, |x| < 4094 — fp16's range after the format's scaling);
         # "auto" (default) = "fp16x3" when every projected weight is below 32 in magnitude, else "bf16x6" (no range limit)
@@ -174,7 +176,7 @@ class DIGAT(GraphEncoder):
                 lp.a = getattr(self, f"{g}_graph_attention_a")[i].weight.data_ptr()
         # bf16x6 projections: split [W | ffn1 | ffn2] of every layer into three bf16 planes (once per weight version)
         P._splits = []
-        if pm in ("bf16x6", "bf16x6-pq3", "pq-bf16", "pq-bf16-x1", "fp16x3") and self.news_embedding_dim % 80 == 0:
+        if pm in ("bf16x6", "bf16x6-pq3", "pq-bf16", "pq-bf16-x1", "pq-fp8", "fp16x3") and self.news_embedding_dim % 80 == 0:
             L_ = _lib.lib()
             d = self.news_embedding_dim
             nbytes = L_.digat_split_weights_bytes(3 * d, d)
@@ -229,7 +231,7 @@ class DIGAT(GraphEncoder):
         """The operand format of this encoder's split weight images: fp16x3 when asked for, and under "auto" / "pq-bf16" whenever
         the range conditions of ``_auto_base`` hold; bf16x6 otherwise."""
         pm = self.projection_mode
-        if pm == "fp16x3" or (pm in ("auto", "pq-bf16") and self._auto_base() == "fp16x3"):
+        if pm == "fp16x3" or (pm in ("auto", "pq-bf16", "pq-fp8") and self._auto_base() == "fp16x3"):
             return _lib.GEMM_F16X3
         return _lib.GEMM_BF16X6
 
@@ -277,10 +279,11 @@ class DIGAT(GraphEncoder):
         DIGAT_NEWS_XATTN_SPARSE (bit 3), ..., DIGAT_PARAMS_BD_TILED (bit 7: ``pass_rows``)."""
         pm = self.projection_mode
         return ({"auto": 0, "dense": 1, "sparse": 2}[self.resolved_xattn_mode("user")]
-                | (4 if pm in ("bf16x6-pq3", "pq-bf16") else 0)
+                | (4 if pm in ("bf16x6-pq3", "pq-bf16", "pq-fp8") else 0)
                 | (8 if self.resolved_xattn_mode("news") == "sparse" else 0)
                 | (16 if pm in ("pq-bf16", "pq-bf16-x1") else 0)         # DIGAT_PQ_BF16: P', Q of Eq. 8 stored in bf16
                 | (32 if pm == "pq-bf16-x1" else 0)                      # DIGAT_PQ_X1: ... and computed with one bf16 product
+                | (256 if pm == "pq-fp8" else 0)                         # DIGAT_PQ_FP8: P', Q of Eq. 8 stored as block-scaled e4m3
                 | (_lib.PARAMS_GEMM_F16X3 if self.gemm_format() == _lib.GEMM_F16X3 else 0)
                 | (_lib.PARAMS_BD_TILED if self.pass_rows >= 2048 else 0))
 

@@ -86,6 +86,17 @@ int digat_xattn_fwd_mode(const float* X, const uint8_t* A, const float* ctx,
                          float* out, int B, int n, int d, int mode,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* One Eq. 8 layer on the reduced-precision operand path of BASELINE configs[4], directly callable (tests, micro-benchmarks):
+ * the projection GEMM on the split image `wsplit` (digat_split_proj_weights(W, F1, F2, d, wsplit, format, ...)) stores P' = K3 + K1
+ * and Q = K2 as bf16 (pq = 1, DIGAT_PQ_BF16) or as block-scaled e4m3 rows (pq = 2, DIGAT_PQ_FP8: the layout documented there),
+ * pq = 0: fp32; the sparse Eq. 8 kernel reads them.  Needs B n >= 2048, n > 16, d % 80 == 0, d <= 1024 (DIGAT_ERR_SHAPE otherwise);
+ * workspace as digat_xattn_fwd.  (graphEncoders.py:143-154 / :163-174; README.md:62-66) */
+int digat_xattn_fwd_lowprec(const float* X, const uint8_t* A, const float* ctx,
+                            const float* W, const float* bW, const float* F1, const float* F2,
+                            const float* F3, const float* b3, const float* a, const void* wsplit, int format,
+                            float* out, int B, int n, int d, int pq,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* The Eq. 8 pairwise part alone, on already-projected inputs: h = X W^T + bW, Q = X F2^T and
  * Pr = (ctx F3^T + b3) + X F1^T, i.e. K3 + K1 already summed in the reference's left-to-right order:
  * score -> leaky_relu(0.2) -> -1e9 mask -> softmax_j (written to alpha [B,n,n], required)
@@ -146,6 +157,13 @@ enum { DIGAT_NEWS_XATTN_SPARSE = 8 };
  * (README.md:62-66).  Ranking metrics move by < 1e-4 (tests/test_hip_lowprec.py); element-wise the contexts move by ~1e-4.
  * Bit 5: the P and Q segments with the leading bf16 product alone (2^-8 per product) instead of the number bit 2 selects. */
 enum { DIGAT_PQ_BF16 = 16, DIGAT_PQ_X1 = 32 };
+/* digat_params.flags bit 8 (BASELINE configs[4], "fp8 Eq.-8 inference path"; same launches as bit 4, which wins when both are
+ * set): the projection GEMM stores P' = K3 + K1 and Q = K2 as BLOCK-SCALED OCP e4m3 (v_cvt_pk_fp8_f32) — one block per (row,
+ * 80-column strip of the GEMM's wave tile), scale = the block's absmax / 448 as fp32, laid out per row as
+ * [d codes | d / 80 scales | pad to 64 bytes] (d = 400: 448 bytes instead of 1 600) — and the Eq. 8 kernel reads 8-code pieces,
+ * rescales in registers (one fma per channel: p s_p + q) and accumulates the score in fp32; h, X and every output stay fp32.
+ * Requires d % 80 == 0.  Measured drift of AUC / MRR / nDCG on the trained reference-pinned dev set: tests/test_hip_lowprec.py. */
+enum { DIGAT_PQ_FP8 = 256 };
 /* digat_params.flags bit 6: every wsplit image of this parameter block (layers' [W|ffn1|ffn2], featureAffine) was split with
  * format DIGAT_GEMM_F16X3 (two scaled fp16 pieces, three products); clear = DIGAT_GEMM_BF16X6.  See digat_split_proj_weights. */
 enum { DIGAT_PARAMS_GEMM_F16X3 = 64 };

@@ -58,7 +58,93 @@ def test_devset_2k_fp32_metrics_match_the_reference():
     assert (np.asarray(ranks) == fx["ranks"].astype(np.int64)).mean() > 0.999
 
 
-@pytest.mark.parametrize("mode", ["pq-bf16", "pq-bf16-x1"])
+def quantize_e4m3_strips(x, strip=80):
+    """The GEMM epilogue's block-scaled OCP e4m3 storage of P' / Q, restated in torch: one block per (row, 80-channel strip),
+    scale = absmax / 448 (fp32), codes = round-to-nearest-even e4m3 of value / scale."""
+    shp = x.shape
+    xs = x.reshape(*shp[:-1], shp[-1] // strip, strip)
+    amax = xs.abs().amax(-1, keepdim=True)
+    scale = torch.where(amax > 0, amax * np.float32(1.0 / 448.0), torch.ones_like(amax))
+    q = (xs * (1.0 / scale)).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).reshape(shp)
+
+
+@pytest.mark.parametrize("pq,fmt", [(0, 0), (1, 0), (2, 0), (2, 1)])
+def test_low_precision_eq8_layer_against_its_emulation(pq, fmt):
+    """digat_xattn_fwd_lowprec: ONE Eq. 8 layer of MIND-shaped user graphs with P' = K3 + K1 and Q = K2 stored in fp32 / bf16 /
+    block-scaled e4m3, against the oracle's unfused Eq. 8 with the same quantiser applied to the two operands before the
+    broadcast-add.  fp32: 1e-5.  Quantised: the projections here and the oracle's differ in the last fp32 bits, so a value
+    that sits on a rounding boundary may take the neighbouring code (1/16 of its magnitude for e4m3) — the outputs then
+    agree to ~1e-3 of their scale in the worst element and much better on average, while quantised and unquantised
+    outputs differ by 10-100x more: layout, scales and strip mapping are what this pins."""
+    import torch.nn.functional as F
+    from digat_amd import _lib, synthetic
+    from oracle import digat_oracle as O
+    B, N, H, C, d, L = 48, 10, 50, 17, 400, 1
+    state = synthetic.make_state_dict(d, C, L, seed=171, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=172, empty_history_rows=(2,))
+    batch["user_graph"][5, 3, :] = False                # a row without any entry: uniform over all nodes (E1)
+    p = O.as_params(state)
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    quant = {0: (lambda x: x), 1: (lambda x: x.to(torch.bfloat16).to(torch.float32)), 2: quantize_e4m3_strips}[pq]
+    pre = "user_graph_attention_"
+    with torch.no_grad():
+        Xu = O.user_nodes(p, tb["user_news_embedding"])
+        c_n = O.news_graph_context(p, tb["news_graph_embeddings"], tb["news_graph_mask"])
+        U = Xu.shape[1]
+        h = O._linear(Xu, p, f"{pre}W.0")
+        K3 = O._linear(c_n, p, f"{pre}ffn3.0").view(B, 1, d)
+        Pq = quant(K3 + O._linear(Xu, p, f"{pre}ffn1.0")).unsqueeze(1)
+        Qq = quant(O._linear(Xu, p, f"{pre}ffn2.0")).unsqueeze(2)
+        s = F.linear(F.relu(Pq + Qq), p[f"{pre}a.0.weight"]).squeeze(3)
+        alpha = F.softmax(F.leaky_relu(s, 0.2).masked_fill(tb["user_graph"] == 0, O.MASK_FILL), dim=2)
+        want = F.relu(torch.bmm(alpha, h)) + Xu
+        exact = O.cross_graph_attention(p, "user", 0, Xu, tb["user_graph"], c_n)
+    Lb = _lib.lib()
+    dev = torch.device(DEV)
+    w = {k: torch.from_numpy(state[f"{pre}{k}"]).to(dev).contiguous() for k in
+         ("W.0.weight", "W.0.bias", "ffn1.0.weight", "ffn2.0.weight", "ffn3.0.weight", "ffn3.0.bias", "a.0.weight")}
+    wsplit = torch.empty(Lb.digat_split_weights_bytes(3 * d, d), dtype=torch.uint8, device=dev)
+    _lib.check(Lb.digat_split_proj_weights(w["W.0.weight"].data_ptr(), w["ffn1.0.weight"].data_ptr(), w["ffn2.0.weight"].data_ptr(), d,
+                                           wsplit.data_ptr(), fmt, _lib.stream_ptr()), "split")
+    dX, dA, dc = Xu.to(dev).contiguous(), tb["user_graph"].to(dev).contiguous(), c_n.to(dev).contiguous()
+    out = torch.full((B, U, d), float("nan"), device=dev)
+    nbytes = Lb.digat_xattn_workspace_bytes(B, U, d)
+    ws = torch.full((nbytes,), 255, dtype=torch.uint8, device=dev)          # NaN patterns: nothing may rely on the scratch
+    _lib.check(Lb.digat_xattn_fwd_lowprec(dX.data_ptr(), dA.data_ptr(), dc.data_ptr(), w["W.0.weight"].data_ptr(), w["W.0.bias"].data_ptr(),
+                                          w["ffn1.0.weight"].data_ptr(), w["ffn2.0.weight"].data_ptr(), w["ffn3.0.weight"].data_ptr(),
+                                          w["ffn3.0.bias"].data_ptr(), w["a.0.weight"].data_ptr(), wsplit.data_ptr(), fmt, out.data_ptr(),
+                                          B, U, d, pq, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_xattn_fwd_lowprec")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    gap = (exact - want).abs()
+    print(f"\n[Eq. 8 layer, pq={pq}, format={fmt}] vs emulation: max {err.max():.3e} mean {err.mean():.3e} (output scale {scale:.2f}); "
+          f"quantised vs exact: max {gap.max():.3e} mean {gap.mean():.3e}")
+    if pq == 0:
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    else:
+        assert err.mean() <= 0.05 * max(float(gap.mean()), 1e-7) + 1e-6, (err.mean(), gap.mean())
+        assert err.max() <= 2e-3 * scale
+        assert gap.max() > 10 * 1e-5, "the quantiser changed nothing: the test does not test"
+
+
+def test_low_precision_eq8_entry_rejects_what_it_cannot_run():
+    from digat_amd import _lib
+    Lb = _lib.lib()
+    t = torch.zeros(64, device=DEV)
+    args = [t.data_ptr()] * 11
+    # d % 80 != 0; n <= 16; fewer than 2048 node rows; unknown pq
+    assert Lb.digat_xattn_fwd_lowprec(*args, 0, t.data_ptr(), 64, 67, 64, 2, t.data_ptr(), 1 << 40, None) == 2
+    assert Lb.digat_xattn_fwd_lowprec(*args, 0, t.data_ptr(), 1024, 10, 400, 2, t.data_ptr(), 1 << 40, None) == 2
+    assert Lb.digat_xattn_fwd_lowprec(*args, 0, t.data_ptr(), 8, 67, 400, 2, t.data_ptr(), 1 << 40, None) == 2
+    assert Lb.digat_xattn_fwd_lowprec(*args, 0, t.data_ptr(), 64, 67, 400, 3, t.data_ptr(), 1 << 40, None) == 1
+    assert Lb.digat_xattn_fwd_lowprec(*args, 0, t.data_ptr(), 64, 67, 400, 2, t.data_ptr(), 16, None) == 3
+
+
+@pytest.mark.parametrize("mode", ["pq-bf16", "pq-bf16-x1", "pq-fp8"])
 def test_bf16_eq8_operands_keep_the_metrics(mode):
     """configs[4]: P' and Q of the user graph's layers >= 1 in bf16 (and, "-x1", computed with one bf16 product).  The metric
     drift against the reference stays within the reference's own 1e-4 criterion; element-wise the scores move by ~1e-4."""
@@ -72,11 +158,13 @@ def test_bf16_eq8_operands_keep_the_metrics(mode):
     drift = np.abs(np.array(metrics) - fx["metrics"])
     print(f"[{mode}] metric drift vs the reference {np.round(drift, 7)}; vs this library's fp32 path "
           f"{np.round(np.abs(np.array(metrics) - np.array(base_metrics)), 7)}")
-    assert rel.mean() < (5e-4 if mode == "pq-bf16" else 2e-3) and rel.max() < 3e-2
+    assert rel.mean() < (5e-4 if mode == "pq-bf16" else 2e-3) and rel.max() < (3e-2 if mode != "pq-fp8" else 0.3)
     if mode == "pq-bf16":
         assert drift.max() <= 1e-4, drift
     else:
-        assert drift.max() <= 5e-4, drift          # one bf16 product for P and Q: reported, held to a looser bound
+        # one bf16 product for P and Q / block-scaled e4m3 on Xavier weights and random clicks (logits of rms ~600, AUC 0.5):
+        # reported, held to a looser bound; the yardstick for "AUC-matched" is the trained model below
+        assert drift.max() <= 5e-4, drift
 
 
 @pytest.mark.parametrize("name", ["devset_default.npz", "devset_tiny.npz"])
@@ -121,7 +209,7 @@ def build_trained():
 
 
 @pytest.mark.parametrize("mode,metric_tol,rank_match", [("bf16x6", 1e-4, 0.9995), ("fp16x3", 1e-4, 0.9995), ("auto", 1e-4, 0.9995),
-                                                        ("pq-bf16", 1e-4, 0.99), ("fp32", 1e-4, 0.9995)])
+                                                        ("pq-bf16", 1e-4, 0.99), ("fp32", 1e-4, 0.9995), ("pq-fp8", 1e-4, 0.95)])
 def test_trained_model_metrics_match_the_reference(mode, metric_tol, rank_match):
     """"AUC-matched" on a model that RANKS: trained weights on the planted-signal corpus (reference AUC 0.644, logits of rms ~10 —
     near-ties between candidates as a trained model has them, not the widely spread scores of Xavier weights on random clicks).
@@ -143,7 +231,7 @@ def test_trained_model_metrics_match_the_reference(mode, metric_tol, rank_match)
     assert metrics[0] > 0.60
     assert drift.max() <= metric_tol, drift
     assert same >= rank_match, same
-    if mode != "pq-bf16":
+    if not mode.startswith("pq-"):
         assert err.max() <= 2e-5 * max(1.0, np.abs(ref).max()), err.max()
 
 
