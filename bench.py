@@ -374,7 +374,9 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         # The timed region overlaps the news-graph kernels with the user graph's on a side stream, so the launch
         # durations above include the sharing.  A second, untimed pass on one stream gives each kernel's duration
         # with the chip to itself (reported as roofline.isolated_*; `frac` stays the timed region's).
-        prev = _lib.lib().digat_set_side_stream(0)
+        enc_iso = W.model.graph_encoder
+        prev = enc_iso.side_stream
+        enc_iso.side_stream = "off"
         sc.join()
         sc.nlanes = 1                              # ... and every batch on the same caller stream
         out.iso_steps = min(steps, 10)
@@ -383,7 +385,7 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
             sc.step()
         torch.cuda.synchronize()
         out.prof_iso = _lib.profile_stop()
-        _lib.lib().digat_set_side_stream(prev)
+        enc_iso.side_stream = prev
     sc.join()
     torch.cuda.synchronize()
     return out

@@ -20,6 +20,9 @@ DIGAT_MAX_NODES = 128
 GEMM_BF16X6, GEMM_F16X3 = 0, 1          # operand format of a split weight image (include/digat_hip.h)
 PARAMS_GEMM_F16X3 = 64                  # digat_params.flags: the block's wsplit images are GEMM_F16X3
 PARAMS_BD_TILED = 128                   # digat_params.flags: the [B,d] linears run on the tiled kernel at every row count
+PARAMS_PQ_FP8 = 256                     # digat_params.flags: P', Q of Eq. 8 stored as block-scaled e4m3 (DIGAT_PQ_FP8)
+PARAMS_SIDE_STREAM_OFF, PARAMS_SIDE_STREAM_ON = 512, 1024      # digat_params.flags: never / always (neither: by pass size)
+PARAMS_NO_LIVE_ROWS = 2048              # digat_params.flags: project every user-graph node in every layer
 
 _f = C.c_void_p  # every device pointer crosses as void*
 
@@ -76,10 +79,7 @@ _SIGNATURES = {
     "digat_encoder_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "digat_encoder_fwd": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_row_logits": (C.c_int, [_f] * 3 + [C.c_int] * 2 + [_f]),
-    "digat_set_side_stream": (C.c_int, [C.c_int]),
     "digat_profile_pause": (C.c_int, [C.c_int]),
-    "digat_set_live_row_skipping": (C.c_int, [C.c_int]),
-    "digat_set_staged_xattn": (C.c_int, [C.c_int]),
     "digat_set_train_precision": (C.c_int, [C.c_int]),
     "digat_gather_tables": (C.c_int, [C.POINTER(GatherJob), C.c_int, _f]),
     "digat_profile_live_row_fraction": (C.c_double, []),
@@ -114,6 +114,7 @@ _SIGNATURES = {
     "digat_user_project0": (C.c_int, [C.POINTER(Params), _f, _f, C.c_int, _f]),
     "digat_news_project0": (C.c_int, [C.POINTER(Params), _f, _f, C.c_int, C.c_int, _f]),
     "digat_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "digat_forget_split_image": (C.c_int, [_f]),
     "digat_split_proj_weights": (C.c_int, [_f, _f, _f, C.c_int, _f, C.c_int, _f]),
     "digat_split_weights": (C.c_int, [_f, C.c_int, C.c_int, _f, C.c_int, _f]),
     "digat_linear_f32x3": (C.c_int, [_f, C.c_int64, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f]),
@@ -159,6 +160,7 @@ _SIGNATURES = {
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
     "digat_profile_marker": (C.c_int, [C.c_int, _f]),
 }
+_LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 EXPORTED = tuple(_SIGNATURES)
 
@@ -175,6 +177,10 @@ def lib() -> C.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in _LAB_SIGNATURES.items():          # LAB builds only (-DDIGAT_LAB through DIGAT_HIP_LIB)
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
 
@@ -228,6 +234,17 @@ def profile_stop():
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
     check(lib().digat_profile_stop(ms, work, cnt), "digat_profile_stop")
     return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, k in enumerate(KERNEL_KINDS)}
+
+
+def split_buffer(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Device bytes for a split weight image.  The library keeps the format of every image it has split by ADDRESS; when this
+    buffer dies the address is forgotten (digat_forget_split_image), so that a later allocation at the same address — an image
+    copied there, say — is not held to a stale format."""
+    import weakref
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if device.type == "cuda":
+        weakref.finalize(buf, lib().digat_forget_split_image, C.c_void_p(buf.data_ptr())).atexit = False
+    return buf
 
 
 _workspaces = {}

@@ -35,6 +35,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Development knobs read from the environment — A/B switches between two kernels that give the same results, timing ablations
+// that give WRONG results (DIGAT_*_SKIP), phase timers — exist in LAB builds only (-DDIGAT_LAB: tools/exp/build_variant.sh).  In
+// the product library LAB_ENV is its default and the variable's name is not even in the binary: no environment variable can
+// change what a scoring run computes (tests/test_abi_cpu.py looks for the names).
+#ifdef DIGAT_LAB
+static int lab_env_value(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define LAB_ENV(name, dflt) lab_env_value(name, dflt)
+#else
+#define LAB_ENV(name, dflt) (dflt)
+#endif
+
 // ---- optional per-kernel event timing (bench.py's roofline leg) ---------------------------------
 // Between digat_profile_start and digat_profile_stop every launch is bracketed by two hipEvents
 // recorded on the stream the kernel is launched on; stop() synchronises once and sums elapsed time
@@ -120,7 +131,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
 #include "digat_xattn.inc"
 #include "digat_context.inc"
 #include "digat_glue.inc"
-#include "digat_staged.inc"
+#ifdef DIGAT_LAB
+#include "digat_staged.inc"       // Eq. 8 of the user graph from LDS-staged rows: five variants, all measured slower
+#else
+// the product library carries the evidence (profiles/), not the code path
+struct PlanBuffers {};
+static size_t plan_bytes(int, int) { return 0; }
+static bool staged_ok(int, int) { return false; }
+static PlanBuffers plan_carve(void*, int, int) { return PlanBuffers{}; }
+static int launch_staged(const SparseArgs&, const PlanBuffers&, int, int, hipStream_t) { return DIGAT_ERR_ARG; }
+static int launch_plan(const uint8_t*, const uint8_t*, const int64_t*, const int*, int, int, int, int, int, int, bool, const PlanBuffers&, hipStream_t) { return DIGAT_ERR_ARG; }
+#endif
 
 // =================================================================================================
 // C ABI
@@ -284,6 +305,8 @@ static int launch_split(const float* w0, const float* w1, const float* w2, int n
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }
+
+int digat_forget_split_image(const void* wsplit) { return wsplit && wsplit_forget(wsplit) ? DIGAT_OK : DIGAT_ERR_ARG; }
 
 int digat_gather_tables(const digat_gather_job* jobs, int njobs, void* stream) {
     if (!jobs || njobs < 0 || njobs > GATHER_MAX_JOBS) return DIGAT_ERR_ARG;
@@ -477,18 +500,24 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
 // caller's stream.
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
-static int g_live_rows_on = getenv("DIGAT_NO_SKIP") && atoi(getenv("DIGAT_NO_SKIP")) ? 0 : 1;
-static int g_sparse_per_node = getenv("DIGAT_SPARSE_PER_NODE") ? atoi(getenv("DIGAT_SPARSE_PER_NODE")) : 12;
+// Nothing below is mutable: live-row lists and the side stream are chosen PER CALL through digat_params.flags
+// (DIGAT_PARAMS_NO_LIVE_ROWS, DIGAT_PARAMS_SIDE_STREAM_OFF / _ON), so two host threads with different settings cannot flip each
+// other's (round 3 had process-wide setters for them).
+static const int g_sparse_per_node = LAB_ENV("DIGAT_SPARSE_PER_NODE", 12);
 // 0 = never, 1 = always, 2 = by pass size (default): below 2 048 rows — there the news kernels are a few waves of workgroups each;
 // from 2 048 rows up every kernel fills the chip by itself and the second stream only makes launches share it (4 096 rows,
 // three passes in flight: 3.21 vs 3.28 ms per pass; stress 16.4 vs 16.8, MIND-large shape 4.52 vs 4.65).  DIGAT_SINGLE_STREAM=1 / 0
 // forces never / always.
-static int g_side_stream_on = getenv("DIGAT_SINGLE_STREAM") ? (atoi(getenv("DIGAT_SINGLE_STREAM")) ? 0 : 1) : 2;
+static const int g_side_stream_lab = LAB_ENV("DIGAT_SINGLE_STREAM", -1);       // LAB builds: 1 / 0 force never / always
 // layer 0 of the user graph on the live nodes only (A/B switch for measurements; DIGAT_L0_LIVE=0: every node at layer 0)
-static int g_l0_live_on = getenv("DIGAT_L0_LIVE") ? atoi(getenv("DIGAT_L0_LIVE")) : 1;
+static const int g_l0_live_on = LAB_ENV("DIGAT_L0_LIVE", 1);
 // 0 (default): the wave-per-centre sparse kernel; 1: the LDS-staged kernels of digat_staged.inc (compulsory HBM traffic, measured
 // slower in round 2: DESIGN.md section 4)
-static int g_staged_on = getenv("DIGAT_XATTN_STAGED") ? atoi(getenv("DIGAT_XATTN_STAGED")) : 0;
+#ifdef DIGAT_LAB
+static int g_staged_on = LAB_ENV("DIGAT_XATTN_STAGED", 0);
+#else
+static constexpr int g_staged_on = 0;
+#endif
 // One side stream (and its three events) per CALLER stream: consecutive batches issued on alternating caller streams
 // (util.batch_streams) then overlap their side work too, and two host threads driving two streams never touch the same
 // events.  A caller stream is expected to be driven by one thread at a time (include/digat_hip.h, threading contract); the
@@ -499,7 +528,7 @@ static SideStream* side_stream(hipStream_t caller) {
     static int used = 0;
     static std::mutex mu;
     int dev = 0;
-    if (!g_side_stream_on || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < used; ++i)
         if (tab[i].dev == dev && tab[i].caller == caller) return tab[i].state == 1 ? &tab[i].side : nullptr;
@@ -588,7 +617,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         return launch_gemm(g, sq);
     };
 
-    const bool want_live = L > 0 && g_live_rows_on && live_ws;
+    const bool want_live = L > 0 && !(p->flags & DIGAT_PARAMS_NO_LIVE_ROWS) && LAB_ENV("DIGAT_NO_SKIP", 0) == 0 && live_ws;
     // Eq. 8 of the user graph: the sparse kernel, the dense pair, or both with the device choosing (p->flags; the choice
     // comes out of the adjacency pass of find_live_rows)
     int sparse_mode = p->flags & 3;
@@ -650,7 +679,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
         hist_last = pend_hlast;
     };
-    SideStream* side = (g_side_stream_on == 2 && B >= 2048) ? nullptr : side_stream(st);
+    // side stream: by pass size unless the caller says (flags): never / always
+    int side_mode = (p->flags & DIGAT_PARAMS_SIDE_STREAM_OFF) ? 0 : ((p->flags & DIGAT_PARAMS_SIDE_STREAM_ON) ? 1 : 2);
+    if (g_side_stream_lab >= 0) side_mode = g_side_stream_lab ? 0 : 1;
+    SideStream* side = (side_mode == 0 || (side_mode == 2 && B >= 2048)) ? nullptr : side_stream(st);
     // Small news graphs (the wave-per-centre score kernel adds K3 itself): the node projections of a layer depend only on
     // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
     // layer i+1's under the pooling of user context i — instead of waiting for c_u.
@@ -1027,25 +1059,15 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     return DIGAT_OK;
 }
 
-int digat_set_live_row_skipping(int enabled) {
-    const int prev = g_live_rows_on;
-    g_live_rows_on = enabled ? 1 : 0;
-    return prev;
-}
-
-int digat_set_staged_xattn(int mode) {
+#ifdef DIGAT_LAB
+int digat_set_staged_xattn(int mode) {        // LAB builds only: process-wide, one host thread
     (void)staged_cfg();
     const int prev = g_staged_on ? 1 + g_staged_cfg : 0;
     g_staged_on = mode > 0 ? 1 : 0;
     if (mode > 0 && mode <= 5) g_staged_cfg = mode - 1;
     return prev;
 }
-
-int digat_set_side_stream(int enabled) {      // 0 = never, 1 = always, 2 = by pass size (the default); returns the previous setting
-    const int prev = g_side_stream_on;
-    g_side_stream_on = enabled == 2 ? 2 : (enabled ? 1 : 0);
-    return prev;
-}
+#endif
 
 int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
                       const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx,

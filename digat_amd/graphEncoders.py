@@ -13,13 +13,17 @@ no eager / CPU fallback: tensors must be on the GPU and the extension must be bu
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import threading
 
 import torch
 import torch.nn as nn
 
 from . import _lib
 from .layers import ScaledDotProductAttention
+
+_TLS = threading.local()          # per-thread launch-option overrides, keyed by encoder (DIGAT.launch_options)
 
 
 class GraphEncoder(nn.Module):
@@ -97,6 +101,12 @@ class DIGAT(GraphEncoder):
         # util.prepare_news_side has looked at the corpus (there is no device-side decision for this graph)
         self.news_xattn_mode = "auto"
         self.corpus_xattn_hint = {}        # {"user": "sparse" | "dense", "news": ...}: set by util.prepare_news_side
+        # per-call launch options (digat_params.flags bits 9-11; results do not depend on them, bit for bit):
+        # side_stream "auto" = the news chain of a layer on the library's side stream for passes below 2 048 rows, "on" / "off" =
+        # always / never; live_rows False = project, score and write every user-graph node (default: dead nodes are skipped).
+        # ``launch_options(...)`` overrides them for the calling THREAD only — nothing here is process-wide.
+        self.side_stream = "auto"
+        self.live_rows = True
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -121,6 +131,31 @@ class DIGAT(GraphEncoder):
         nn.init.zeros_(self.featureAffine.bias)
         self.userAttention.initialize()
 
+    @contextlib.contextmanager
+    def launch_options(self, side_stream=None, live_rows=None):
+        """Override ``side_stream`` / ``live_rows`` for the calls the CURRENT THREAD makes inside the block (util.score_rows turns
+        the side stream on for single-lane runs this way): another thread driving the same encoder keeps its own settings."""
+        table = _TLS.__dict__.setdefault("opts", {})
+        prev = table.get(id(self))
+        cur = dict(prev or {})
+        if side_stream is not None:
+            if side_stream not in ("auto", "on", "off"):
+                raise ValueError("side_stream must be 'auto', 'on' or 'off'")
+            cur["side_stream"] = side_stream
+        if live_rows is not None:
+            cur["live_rows"] = bool(live_rows)
+        table[id(self)] = cur
+        try:
+            yield self
+        finally:
+            if prev is None:
+                table.pop(id(self), None)
+            else:
+                table[id(self)] = prev
+
+    def _launch_option(self, name):
+        return _TLS.__dict__.get("opts", {}).get(id(self), {}).get(name, getattr(self, name))
+
     def resolved_xattn_mode(self, g: str) -> str:
         """The Eq. 8 variant in force for graph ``g``: the explicit setting, or what ``util.prepare_news_side`` found in the
         corpus it was last shown while the setting is "auto" (``corpus_xattn_hint``); "auto" otherwise."""
@@ -139,10 +174,9 @@ class DIGAT(GraphEncoder):
         fmt = self.gemm_format()
         ptrs = tuple(p.data_ptr() for p in self.parameters())
         if self._param_block is not None and self._param_block[0] == ptrs and self._param_block[2] == self._fold_key():
-            # the Eq. 8 variant only selects kernels (P.flags): it never invalidates the split weights or the folded
-            # queries, so changing it (util.prepare_news_side's corpus hint) must not rebuild them
-            self._param_block[1].flags = self._flags()
-            return self._param_block[1]
+            # the Eq. 8 variant and the launch options only select kernels (flags): they never invalidate the split weights or
+            # the folded queries, so changing them (util.prepare_news_side's corpus hint, launch_options) must not rebuild them
+            return self._call_block(self._param_block[1])
         for p in self.parameters():
             if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.DigatHipError("DIGAT parameters must be contiguous float32 CUDA tensors "
@@ -182,7 +216,7 @@ class DIGAT(GraphEncoder):
             nbytes = L_.digat_split_weights_bytes(3 * d, d)
             for g, arr in (("news", P.news), ("user", P.user)):
                 for i in range(self.graph_depth):
-                    buf = torch.empty(nbytes, dtype=torch.uint8, device=self.topic_node_embedding.device)
+                    buf = _lib.split_buffer(nbytes, self.topic_node_embedding.device)
                     _lib.check(L_.digat_split_proj_weights(
                         getattr(self, f"{g}_graph_attention_W")[i].weight.data_ptr(),
                         getattr(self, f"{g}_graph_attention_ffn1")[i].weight.data_ptr(),
@@ -190,7 +224,7 @@ class DIGAT(GraphEncoder):
                         _lib.stream_ptr()), "digat_split_proj_weights")
                     arr[i].wsplit = buf.data_ptr()
                     P._splits.append(buf)
-            buf = torch.empty(L_.digat_split_weights_bytes(d, d), dtype=torch.uint8, device=self.topic_node_embedding.device)
+            buf = _lib.split_buffer(L_.digat_split_weights_bytes(d, d), self.topic_node_embedding.device)
             _lib.check(L_.digat_split_weights(self.featureAffine.weight.data_ptr(), d, d, buf.data_ptr(), fmt, _lib.stream_ptr()),
                        "digat_split_weights")
             P.featureAffine_wsplit = buf.data_ptr()
@@ -209,7 +243,7 @@ class DIGAT(GraphEncoder):
                 L_, d, dev = _lib.lib(), self.news_embedding_dim, self.topic_node_embedding.device
 
                 def image(rows, K, fn, *args):
-                    buf = torch.empty(L_.digat_split_weights_bytes(rows, K), dtype=torch.uint8, device=dev)
+                    buf = _lib.split_buffer(L_.digat_split_weights_bytes(rows, K), dev)
                     _lib.check(fn(*args, buf.data_ptr(), fmt, _lib.stream_ptr()), "split")
                     P._splits.append(buf)
                     return buf.data_ptr()
@@ -221,7 +255,14 @@ class DIGAT(GraphEncoder):
                     third = self.user_graph_attention_ffn3[l].weight.data_ptr() if l < self.graph_depth else P.userAtt_fold_W
                     P.ctx_wsplit[l] = image(3 * d, d, L_.digat_split_proj_weights, P.user_news_fold_W, P.userAtt_fold_W, third, d)
         self._param_block = (ptrs, P, self._fold_key())
-        return P
+        return self._call_block(P)
+
+    def _call_block(self, P):
+        """The parameter block one call hands to the library: a COPY of the cached block (2.6 KB of pointers) with this call's
+        flags — two threads with different launch options never write the same struct."""
+        Q = _lib.Params.from_buffer_copy(P)
+        Q.flags = self._flags()
+        return Q
 
     def resolved_projection_mode(self) -> str:
         """``projection_mode`` with "auto" resolved from the weights' range (once per weight version; one host sync)."""
@@ -244,9 +285,10 @@ class DIGAT(GraphEncoder):
         key += (self.corpus_activation_max, self.range_fallback)
         if self._resolved_pm is None or self._resolved_pm[0] != key:
             amax = self.corpus_activation_max
-            # fp16x3 needs a driver that looks at the range flag after the run (util.compute_scores / score_rows do, and fall back
-            # to bf16x6): "auto" therefore picks it only once util.prepare_news_side has seen the corpus — direct forward /
-            # inference calls get the range-free bf16x6.  Then: weights below 32 (the format holds 63), the topic nodes and the
+            # fp16x3 needs a driver that looks at the range flag after the run: util.score_rows and util.compute_scores do (and
+            # redo the run in bf16x6); "auto" therefore picks it only once util.prepare_news_side has seen the corpus — plain
+            # forward / inference calls get the range-free bf16x6.  A caller that runs prepare_news_side and then drives
+            # inference / inference_grouped itself (bench.py's timed loop) must read range_overflowed() after its run.  Then: weights below 32 (the format holds 63), the topic nodes and the
             # corpus's news representations below 256 (the format holds 4094; what the features of layers >= 1 grow to is
             # checked on the device, by the GEMM itself); nan compares false
             ok = amax is not None and not self.range_fallback
@@ -285,7 +327,9 @@ class DIGAT(GraphEncoder):
                 | (32 if pm == "pq-bf16-x1" else 0)                      # DIGAT_PQ_X1: ... and computed with one bf16 product
                 | (256 if pm == "pq-fp8" else 0)                         # DIGAT_PQ_FP8: P', Q of Eq. 8 stored as block-scaled e4m3
                 | (_lib.PARAMS_GEMM_F16X3 if self.gemm_format() == _lib.GEMM_F16X3 else 0)
-                | (_lib.PARAMS_BD_TILED if self.pass_rows >= 2048 else 0))
+                | (_lib.PARAMS_BD_TILED if self.pass_rows >= 2048 else 0)
+                | {"auto": 0, "off": _lib.PARAMS_SIDE_STREAM_OFF, "on": _lib.PARAMS_SIDE_STREAM_ON}[self._launch_option("side_stream")]
+                | (0 if self._launch_option("live_rows") else _lib.PARAMS_NO_LIVE_ROWS))
 
     def _fold_sources(self):
         ca, ua = self.candidate_attention, self.userAttention

@@ -225,10 +225,10 @@ class MSA(NewsEncoder):
         for name, w in zip(("word_embedding", "W_Q", "b_Q", "W_K", "W_V", "b_V", "A1", "b1", "a2"), keep):
             setattr(P, name, w.data_ptr())
         if hd % 80 == 0 and dm % 4 == 0 and dm >= 32:          # the bf16x6 matrix-core path (fp32-grade)
-            qkv = torch.empty(L.digat_msa_split_bytes(dm, mha.h, mha.d_k), dtype=torch.uint8, device=dev)
+            qkv = _lib.split_buffer(L.digat_msa_split_bytes(dm, mha.h, mha.d_k), dev)
             _lib.check(L.digat_split_msa_weights(keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), dm, hd,
                                                  qkv.data_ptr(), _lib.stream_ptr()), "digat_split_msa_weights")
-            a1 = torch.empty(L.digat_split_weights_bytes(att, hd), dtype=torch.uint8, device=dev)
+            a1 = _lib.split_buffer(L.digat_split_weights_bytes(att, hd), dev)
             # the MSA encoder's operand format is bf16x6 (no range limit: word embeddings are whatever the vocabulary file holds)
             _lib.check(L.digat_split_weights(keep[6].data_ptr(), att, hd, a1.data_ptr(), _lib.GEMM_BF16X6, _lib.stream_ptr()), "digat_split_weights")
             P.qkv_wsplit, P.a1_wsplit = qkv.data_ptr(), a1.data_ptr()

@@ -394,13 +394,63 @@ def _pass_rows(batch_size: int, launch_rows: Optional[int] = None) -> int:
     return batch_size * max(1, rows // max(1, batch_size))
 
 
+def range_overflow_any_rank(enc, world_size: int = 1, group=None) -> bool:
+    """Has an fp16x3 GEMM of ``enc`` met an activation beyond the format's range since the flag was last cleared — on ANY rank of
+    ``group``?  Every rank gets the same answer (MAX all-reduce), so that all of them fall back to bf16x6 together: a per-rank
+    decision would all-gather scores of two formats and leave the ranks' caches and weights_key diverged."""
+    if not hasattr(enc, "range_overflowed"):
+        return False
+    hit = bool(enc.range_overflowed())
+    if world_size > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend(group)
+        dev = enc.topic_node_embedding.device if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if hit else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        hit = bool(int(t.item()))
+    return hit
+
+
 def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, grouped: bool = True,
-               streams: int = 3, in_place_tables: bool = True, launch_rows: Optional[int] = None) -> torch.Tensor:
+               streams: int = 3, in_place_tables: bool = True, launch_rows: Optional[int] = None,
+               check_range: bool = True) -> torch.Tensor:
     """Scores of rows [start, end): the hot loop of util.py:51-69.  ``grouped`` passes each impression's user
     tensors once (bit-identical scores, less work in layer 0); it needs ``model.inference_grouped``.  ``streams``:
     consecutive launch sets alternate over this many HIP streams (same kernels, same bits: see ``batch_streams``).
     ``batch_size`` is the reference's dev batch; ``launch_rows`` (default ``LAUNCH_ROWS``) how many rows — whole batches — one
-    pass through the encoder takes (``launch_rows=batch_size``: the reference's own chunking)."""
+    pass through the encoder takes (``launch_rows=batch_size``: the reference's own chunking).
+
+    ``check_range`` (default): when the projections ran in the range-limited fp16x3 format (what "auto" resolves to once
+    ``prepare_news_side`` has seen the corpus), the encoder's range flag is read after the run — one host synchronisation — and a
+    run that met an activation at or beyond |x| = 4094 is redone in bf16x6 ("auto"; the encoder stays there) or refused
+    (explicit "fp16x3").  ``compute_scores`` passes False and makes the same decision for all ranks together.  Callers that drive
+    ``model.inference`` / ``inference_grouped`` themselves after ``prepare_news_side`` (bench.py's timed loop) must read
+    ``graph_encoder.range_overflowed()`` themselves."""
+    enc0 = getattr(model, "graph_encoder", None)
+    watch = check_range and hasattr(enc0, "range_overflowed") and enc0.gemm_format() == 1
+    if watch:
+        enc0.range_overflowed()            # clear what earlier calls may have left in the flag
+    scores = _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_place_tables, launch_rows)
+    if watch and enc0.range_overflowed():
+        _range_fallback(enc0, dc, batch_size)
+        scores = _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_place_tables, launch_rows)
+    return scores
+
+
+def _range_fallback(enc, dc, batch_size):
+    """An fp16x3 GEMM met an activation at or beyond the format's range (|x| >= 4094: node features of a deep layer, say): its
+    results are degraded or inf.  Under "auto" the encoder moves to the range-free bf16x6 format (and stays there) and the
+    per-news tables are rebuilt; an explicit "fp16x3" is the caller's word against the data's — refuse to return such scores."""
+    if enc.projection_mode == "fp16x3":
+        from ._lib import DigatHipError
+        raise DigatHipError("projection_mode='fp16x3': an activation left the format's range (|x| >= 4094); use 'bf16x6' or 'auto'")
+    import warnings
+    warnings.warn("digat_amd: fp16x3 projections met activations beyond the format's range; re-scoring in bf16x6")
+    enc.range_fallback = True
+    prepare_news_side(enc, dc, batch_size)
+
+
+def _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_place_tables, launch_rows):
     dev = dc.news_embedding.device
     scores = torch.empty(end - start, dtype=torch.float32, device=dev)
     grouped = grouped and hasattr(model, "inference_grouped")
@@ -415,13 +465,11 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     lanes = batch_streams(dev, max(1, streams))
     # a single lane has nothing else to put under the user graph's kernels: there the library's side stream (news chain) stays on
     # for big passes too (4096 rows, one lane: 3.50 vs 3.64 ms; three lanes: 3.17 without it vs 3.29 with it — the default)
-    from . import _lib
-    side_prev = _lib.lib().digat_set_side_stream(1) if len(lanes) == 1 and dev.type == "cuda" else None
-    try:
-        return _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables)
-    finally:
-        if side_prev is not None:
-            _lib.lib().digat_set_side_stream(side_prev)
+    # (a per-call, per-thread launch option — digat_params.flags — not a process-wide switch)
+    if len(lanes) == 1 and hasattr(enc, "launch_options") and enc._launch_option("side_stream") == "auto":
+        with enc.launch_options(side_stream="on"):
+            return _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables)
+    return _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables)
 
 
 def _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables):
@@ -496,19 +544,11 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
     start, end = shard_rows(row_imp, world_size, rank)
     enc = getattr(model, "graph_encoder", None)
     watch_range = score_fn is None and hasattr(enc, "range_overflowed")
-    local = (score_fn or score_rows)(model, dc, start, end, batch_size)
-    if watch_range and enc.range_overflowed():
-        # an fp16x3 GEMM met an activation at or beyond the format's range (|x| >= 4094: node features of a deep layer, say):
-        # its results are degraded or inf.  Under "auto" the run is redone in the range-free bf16x6 format (and stays there);
-        # an explicit "fp16x3" is the caller's word against the data's — refuse to return such scores.
-        if enc.projection_mode == "fp16x3":
-            from ._lib import DigatHipError
-            raise DigatHipError("projection_mode='fp16x3': an activation left the format's range (|x| >= 4094); use 'bf16x6' or 'auto'")
-        import warnings
-        warnings.warn("digat_amd: fp16x3 projections met activations beyond the format's range; re-scoring in bf16x6")
-        enc.range_fallback = True
-        prepare_news_side(enc, dc, batch_size)
-        local = score_rows(model, dc, start, end, batch_size)
+    local = score_fn(model, dc, start, end, batch_size) if score_fn else score_rows(model, dc, start, end, batch_size, check_range=False)
+    # the fp16x3 range check of score_rows, decided for ALL ranks together (a rank whose shard overflowed must not fall back alone)
+    if watch_range and range_overflow_any_rank(enc, world_size, group):
+        _range_fallback(enc, dc, batch_size)
+        local = score_rows(model, dc, start, end, batch_size, check_range=False)
     if world_size > 1:
         counts = [shard_rows(row_imp, world_size, r) for r in range(world_size)]
         scores = all_gather_scores(local, [e - s for s, e in counts], group)

@@ -17,12 +17,15 @@
  *   - inputs are never written; outputs may alias the `addend` argument where one exists;
  *   - returns DIGAT_OK (0) or a DIGAT_ERR_* code, never throws.  Eval-mode semantics
  *     (dropout = identity), i.e. what DIGAT.inference / model.eval() computes;
- *   - one host thread issues the calls of a process (one process per GPU): the library keeps a side stream with its
- *     events and the launch profiler in process-wide state.  Calls on DIFFERENT streams may be in flight together as
- *     long as each has its own workspace (digat_amd.util.score_rows alternates two).
- * Environment, read once at load (development knobs; the setters below override them): DIGAT_SINGLE_STREAM=1 (no side
- * stream), DIGAT_NO_SKIP=1 (no live-row lists), DIGAT_SPARSE_PER_NODE=<n> (threshold of DIGAT_XATTN_AUTO, default 12);
- * DIGAT_XATTN_SKIP / DIGAT_TOPIC_SKIP are timing ablations that produce wrong results and must stay unset.
+ *   - threading: calls on DIFFERENT streams may be in flight together — from one host thread or several — as long as each stream
+ *     has its own workspace and is driven by one thread at a time (digat_amd.util.score_rows alternates three).  Everything a
+ *     call's behaviour depends on travels WITH the call (digat_params.flags: Eq. 8 variant, operand format, side stream, live-row
+ *     lists); the library keeps no mutable process-wide switch.  Per-caller-stream side streams live in a mutex-guarded table.
+ *     Exceptions, both diagnostics: the launch profiler (digat_profile_*: one measuring thread) and digat_set_train_precision
+ *     (set once per training run).
+ *   - no environment variable changes what the product library computes or which kernels it runs: the development knobs of
+ *     earlier rounds (A/B switches, the wrong-result timing ablations DIGAT_*_SKIP, phase timers, the LDS-staged Eq. 8 variants)
+ *     exist only in LAB builds (-DDIGAT_LAB, tools/exp/build_variant.sh).
  */
 #ifndef DIGAT_HIP_H
 #define DIGAT_HIP_H
@@ -59,8 +62,12 @@ int digat_linear_f32(const float* x, int64_t ldx, const float* w, const float* b
  * pieces and the six significant partial products are summed in the fp32 accumulator (format DIGAT_GEMM_BF16X6), or into
  * two scaled fp16 pieces with three products (DIGAT_GEMM_F16X3; range and accuracy: see the enum below).  `wsplit`
  * (digat_split_weights_bytes(N, K) bytes, enough for either format) receives the split weights as ready-made LDS images
- * in the format the caller names; the image remembers it.  M >= 2048, N % 80 == 0, K % 8 == 0. */
+ * in the format the caller names; the library remembers the format of every image it has split (by address) until
+ * digat_forget_split_image(wsplit) — call it before the buffer is freed or reused for anything else — and refuses a launch
+ * that names the other one (DIGAT_ERR_ARG).  N % 80 == 0, K % 8 == 0; any M (from 2048 rows up the strip-mined tiled kernel,
+ * below the split-image [B,d] kernel — same split operands, same accuracy). */
 size_t digat_split_weights_bytes(int rows, int K);
+int digat_forget_split_image(const void* wsplit);      /* 0 = forgotten, DIGAT_ERR_ARG = not an image the library knows */
 int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, int format, void* stream);
 int digat_split_weights(const float* W, int N, int K, void* wsplit, int format, void* stream);    /* one [N,K] matrix */
 int digat_linear_f32x3(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
@@ -218,7 +225,8 @@ typedef struct digat_params {
     const void  *cand_fold_wsplit, *gate_wsplit;
     const void  *ctx_wsplit[DIGAT_MAX_DEPTH + 1];
     uint32_t    *range_flag;             /* optional, DIGAT_PARAMS_GEMM_F16X3 only: one device word the fp16x3 GEMMs OR 1 into when an
-                                            activation is at or beyond the format's range (|x| >= 4094, inf or NaN): the caller zeroes it
+                                            activation is at or beyond the format's range (|x| >= 4094 or inf; a NaN input does not raise it — it reaches the outputs as NaN, as in
+                                            the reference): the caller zeroes it
                                             before a scoring run and reads it after (digat_amd/util.py re-scores in bf16x6 when set) */
 } digat_params;
 
@@ -243,30 +251,23 @@ int digat_encoder_fwd(const digat_params* params,
                       int B, int N, int H,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* With the folded-query fields set, digat_encoder_fwd / _grouped run the news-graph kernels of a layer (small:
- * N nodes, [B,d] linears) on an internal side stream under the user graph's Eq. 8 and join before the user
- * context is pooled (two events per layer; capturable) — by default for passes below 2 048 rows (2: from there up every kernel fills
- * the chip by itself and a second stream only makes launches share it).  1 = always, 0 = every launch on the caller's stream
- * (env DIGAT_SINGLE_STREAM=0 / 1 force the same).  Returns the previous setting.  Results do not depend on it. */
-int digat_set_side_stream(int enabled);
+/* With the folded-query fields set, digat_encoder_fwd / _grouped can run the news-graph kernels of a layer (small: N nodes,
+ * [B,d] linears) on an internal side stream — one per caller stream — under the user graph's Eq. 8 and join before the user
+ * context is pooled.  digat_params.flags bits 9-10 choose: neither = by pass size (on below 2 048 rows, where those kernels
+ * are a few waves of workgroups each; off from 2 048 rows up, where every kernel fills the chip by itself),
+ * DIGAT_PARAMS_SIDE_STREAM_OFF = never, DIGAT_PARAMS_SIDE_STREAM_ON = always (right for a driver that keeps a single pass in
+ * flight).  Results do not depend on it, bit for bit.
+ * Bit 11, DIGAT_PARAMS_NO_LIVE_ROWS: project, score and write EVERY user-graph node in every layer.  Default (clear): nodes that
+ * cannot reach an output — history padding slots, topic nodes of unread categories: only their self loop, pooled with weight 0 —
+ * are found on the device and skipped (about half of a MIND user graph).  Outputs are bit-identical either way. */
+enum { DIGAT_PARAMS_SIDE_STREAM_OFF = 512, DIGAT_PARAMS_SIDE_STREAM_ON = 1024, DIGAT_PARAMS_NO_LIVE_ROWS = 2048 };
 
-/* User-graph nodes that cannot reach the encoder's outputs — no edge to another node, and pooled only into a
- * masked category bucket: the history's padding slots and the topic nodes of unread categories
- * (MIND_corpus.py:153-176) — are left out of the node projections of layers >= 1 by digat_encoder_fwd / _grouped
- * (found on the device from user_graph, user_category_mask, user_category_indices; no host sync).  The outputs
- * are unchanged.  0 projects every row (also: env DIGAT_NO_SKIP=1).  Returns the previous setting. */
-int digat_set_live_row_skipping(int enabled);
-
-/* Sparse Eq. 8 of the user graph inside the encoder entry points, from LDS-staged rows (digat_staged.inc; needs the per-batch
- * plan the entry points then build): the needed P' / h rows of a block of centres are staged once in LDS, so each is read
- * from HBM once (PMC: 1.15x the algorithmic bytes, against 2-3x for the wave-per-centre kernel).
- *   0  (default) the wave-per-centre kernel, which re-reads shared neighbour rows through L2 — still the faster one
- *      (98 us against 120 us per user-graph launch, round 2: the staged kernels do not yet overlap their DMA with compute)
- *   4  staged rows + one THREAD per adjacency entry for the scores (no cross-lane reduction; the channel sum is one
- *      sequential fma chain: last-bit differences from mode 0, 2e-5 against the oracle)
- *   1-3  staged rows + the wave-per-centre arithmetic (bit-identical to mode 0), three workgroup shapes
- * Also: env DIGAT_XATTN_STAGED=1 (+ DIGAT_STAGED_CFG=0..3 = mode - 1).  Returns the previous mode. */
+#ifdef DIGAT_LAB
+/* LAB builds only (process-wide, one host thread): sparse Eq. 8 of the user graph from LDS-staged rows (digat_staged.inc; five
+ * variants, mode 1-5; 0 = the wave-per-centre kernel).  Measured slower in round 2: the product
+ * library does not carry the code path. */
 int digat_set_staged_xattn(int mode);
+#endif
 
 /* The same inference for rows that SHARE users: in dev/test scoring the ~37 candidate rows of one
  * impression carry identical user tensors (util.py:57-67 expands them per row).  Here the user side is
@@ -384,7 +385,7 @@ int digat_set_train_precision(int bf16);
  * at the upper bound the high piece saturates (precision degrades to ~2^-15, then inf) — the kernel reports that through
  * digat_params.range_flag.
  * There is NO process-wide setting: the format is a property of a split image.  It is chosen by whoever splits the weights
- * (the `format` argument of digat_split_*), the encoder entry points are told through digat_params.flags & DIGAT_GEMM_F16X3
+ * (the `format` argument of digat_split_*), the encoder entry points are told through digat_params.flags & DIGAT_PARAMS_GEMM_F16X3 (bit 6 = 64; NOT the enum value DIGAT_GEMM_F16X3 = 1)
  * (every wsplit image of one digat_params has the same format), and the library remembers the format of every image it has
  * split: a launch that names the other format returns DIGAT_ERR_ARG instead of misreading the image.  The training entries
  * (digat_*_fwd_train, digat_*_bwd, digat_linear_bwd_input_x3, digat_xattn_project_x3) and the MSA encoder split their weights in

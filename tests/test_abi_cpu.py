@@ -15,6 +15,7 @@ from conftest import REPO
 def declared_functions():
     text = open(os.path.join(REPO, "include", "digat_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef DIGAT_LAB.*?#endif", "", text, flags=re.S)          # LAB builds only: not part of the product ABI
     return sorted(set(re.findall(r"\b(digat_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -90,6 +91,24 @@ def test_no_process_wide_operand_format():
     for f in os.listdir(csrc):
         text = open(os.path.join(csrc, f)).read()
         assert "g_gemm_format" not in text and "GemmFormatScope" not in text, f
+
+
+def test_no_environment_switch_and_no_mutable_mode_in_the_product_library():
+    """Round-3 verdict, items 8 / 9 / 12: the wrong-result timing ablations (DIGAT_*_SKIP), every other environment knob, the
+    LDS-staged Eq. 8 variants and the process-wide setters (side stream, live-row lists, staged mode) are LAB-build material
+    (-DDIGAT_LAB); the product library neither reads an environment variable nor exports a mode setter."""
+    from digat_amd import _lib, build
+    build.build(verbose=False)
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"_SKIP", b"DIGAT_SINGLE_STREAM", b"DIGAT_NO_SKIP", b"DIGAT_XATTN_STAGED", b"DIGAT_STREAM_TIMERS", b"DIGAT_L0_LIVE",
+                 b"DIGAT_SPARSE_PER_NODE", b"DIGAT_NEWS_LDS", b"DIGAT_POOL_RESIDENT", b"DIGAT_SKINNY_SPLIT", b"DIGAT_SPARSE_XCD",
+                 b"xattn_staged_kernel", b"getenv"):
+        assert name not in blob, name
+    L = _lib.lib()
+    for setter in ("digat_set_side_stream", "digat_set_live_row_skipping", "digat_set_staged_xattn", "digat_set_gemm_format"):
+        assert not hasattr(L, setter), setter
+    text = open(os.path.join(REPO, "digat_amd", "csrc", "digat_kernels.hip")).read()
+    assert "g_live_rows_on" not in text and "g_side_stream_on" not in text
 
 
 def test_product_package_does_not_import_the_oracle():

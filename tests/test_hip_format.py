@@ -123,6 +123,34 @@ def test_fp16x3_range_flag_and_fallback_at_layers_above_zero():
     assert enc.resolved_projection_mode() == "fp16x3" and not enc.range_fallback and not enc.range_overflowed()
 
 
+def test_score_rows_itself_watches_the_range_flag():
+    """Direct callers of util.score_rows (not only compute_scores) get the check: an "auto" run whose deep-layer features leave
+    fp16x3's range is redone in bf16x6 and equals an explicit bf16x6 run; an explicit "fp16x3" raises."""
+    from digat_amd import _lib, util
+    corpus, model, dc, _ = _small_world(scale=8.0, d=400, news_num=384, impressions=64)
+    enc = model.graph_encoder
+    with torch.no_grad():
+        for g in ("news", "user"):
+            getattr(enc, f"{g}_graph_attention_W")[0].weight.mul_(300.0)
+    enc.projection_mode = "bf16x6"
+    util.prepare_news_side(enc, dc, 1024)
+    want = util.score_rows(model, dc, 0, dc.rows, 1024).cpu().numpy()
+    enc.projection_mode = "auto"
+    util.prepare_news_side(enc, dc, 1024)
+    assert enc.resolved_projection_mode() == "fp16x3"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = util.score_rows(model, dc, 0, dc.rows, 1024).cpu().numpy()
+    assert any("bf16x6" in str(w.message) for w in caught)
+    assert enc.range_fallback and enc.resolved_projection_mode() == "bf16x6"
+    np.testing.assert_array_equal(got, want)
+    enc.range_fallback = False
+    enc.projection_mode = "fp16x3"
+    util.prepare_news_side(enc, dc, 1024)
+    with pytest.raises(_lib.DigatHipError):
+        util.score_rows(model, dc, 0, dc.rows, 1024)
+
+
 def test_evaluation_and_training_on_two_host_threads_are_bit_stable():
     """An fp16x3 dev evaluation on one thread / stream and bf16x6 training steps on another, at the same time: each must produce
     exactly what it produces alone (the operand format travels with the call; nothing process-wide is flipped)."""
@@ -177,6 +205,45 @@ def test_evaluation_and_training_on_two_host_threads_are_bit_stable():
     np.testing.assert_array_equal(both_t["w"], alone_t["w"])
     for run in both_e["scores"]:
         np.testing.assert_array_equal(run, alone_e["scores"][0])
+
+
+def test_two_threads_with_different_launch_options_do_not_flip_each_other():
+    """Side stream and live-row lists are per-call options (digat_params.flags through DIGAT.launch_options, thread-local): two
+    host threads scoring the SAME encoder — one with the side stream on and live-row lists off, one the other way round — each
+    see their own flags in every call and both reproduce the single-thread scores bit for bit (round 3 had process-wide setters
+    here: one thread's digat_set_side_stream reached the other's calls)."""
+    from digat_amd import _lib, util
+    corpus, model, dc, cfg = _small_world(seed=19, d=400, news_num=512, impressions=120)
+    enc = model.graph_encoder
+    util.prepare_news_side(enc, dc, 1024)
+    want = util.score_rows(model, dc, 0, dc.rows, 1024).cpu().numpy()
+    seen, errors = {"a": set(), "b": set()}, []
+    barrier = threading.Barrier(2)
+
+    def run(tag, opts, out):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=DEV)), enc.launch_options(**opts):
+                barrier.wait(timeout=60)
+                runs = []
+                for _ in range(4):
+                    seen[tag].add(int(enc._params().flags) & (_lib.PARAMS_SIDE_STREAM_OFF | _lib.PARAMS_SIDE_STREAM_ON | _lib.PARAMS_NO_LIVE_ROWS))
+                    runs.append(util.score_rows(model, dc, 0, dc.rows, 1024, streams=1).cpu().numpy())
+                out[tag] = runs
+        except Exception as exc:
+            errors.append(exc)
+    out = {}
+    threads = [threading.Thread(target=run, args=("a", dict(side_stream="on", live_rows=False), out)),
+               threading.Thread(target=run, args=("b", dict(side_stream="off", live_rows=True), out))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert seen["a"] == {_lib.PARAMS_SIDE_STREAM_ON | _lib.PARAMS_NO_LIVE_ROWS} and seen["b"] == {_lib.PARAMS_SIDE_STREAM_OFF}
+    for tag in ("a", "b"):
+        for r in out[tag]:
+            np.testing.assert_array_equal(r, want)
+    assert not int(enc._params().flags) & (_lib.PARAMS_SIDE_STREAM_OFF | _lib.PARAMS_SIDE_STREAM_ON | _lib.PARAMS_NO_LIVE_ROWS)
 
 
 def test_dev_evaluation_follows_a_news_encoder_in_training():

@@ -434,15 +434,18 @@ def test_side_stream_schedule_is_bit_identical_to_single_stream(neighbors, hops,
     model = model.to(_dev()).eval()
     dc = util.DeviceCorpus.from_numpy(corpus, _dev())
     util.prepare_news_side(model.graph_encoder, dc, 1024)
-    prev = _lib.lib().digat_set_side_stream(0)
-    try:
-        single = util.score_rows(model, dc, 0, dc.rows, 1024)
-        _lib.lib().digat_set_side_stream(1)
-        for _ in range(3):                   # a race would not reproduce the same bits three times
-            both = util.score_rows(model, dc, 0, dc.rows, 1024)
-            assert torch.equal(single, both)
-    finally:
-        _lib.lib().digat_set_side_stream(prev)
+    enc = model.graph_encoder
+    enc.side_stream = "off"                  # digat_params.flags & DIGAT_PARAMS_SIDE_STREAM_OFF: a per-call option
+    single = util.score_rows(model, dc, 0, dc.rows, 1024)
+    enc.side_stream = "on"
+    for _ in range(3):                       # a race would not reproduce the same bits three times
+        both = util.score_rows(model, dc, 0, dc.rows, 1024)
+        assert torch.equal(single, both)
+    enc.side_stream = "auto"
+    with enc.launch_options(side_stream="off"):          # the thread-local override
+        assert enc._params().flags & _lib.PARAMS_SIDE_STREAM_OFF
+        assert torch.equal(util.score_rows(model, dc, 0, dc.rows, 1024), single)
+    assert not enc._params().flags & (_lib.PARAMS_SIDE_STREAM_OFF | _lib.PARAMS_SIDE_STREAM_ON)
 
 
 @pytest.mark.parametrize("seed,impressions,max_c,quant", [(1, 300, 40, 0), (2, 50, 300, 8), (3, 1, 2, 0), (4, 2000, 60, 4)])
@@ -489,15 +492,13 @@ def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     model = model.to(_dev()).eval()
     dc = util.DeviceCorpus.from_numpy(corpus, _dev())
     util.prepare_news_side(model.graph_encoder, dc, 1024)
-    prev = _lib.lib().digat_set_live_row_skipping(0)
-    try:
-        every = util.score_rows(model, dc, 0, dc.rows, 1024)
-        every_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
-        _lib.lib().digat_set_live_row_skipping(1)
-        live = util.score_rows(model, dc, 0, dc.rows, 1024)
-        live_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
-    finally:
-        _lib.lib().digat_set_live_row_skipping(prev)
+    model.graph_encoder.live_rows = False          # digat_params.flags & DIGAT_PARAMS_NO_LIVE_ROWS
+    assert model.graph_encoder._params().flags & _lib.PARAMS_NO_LIVE_ROWS
+    every = util.score_rows(model, dc, 0, dc.rows, 1024)
+    every_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+    model.graph_encoder.live_rows = True
+    live = util.score_rows(model, dc, 0, dc.rows, 1024)
+    live_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
     assert torch.equal(every, every_per_row)
     assert torch.equal(live, every)
     assert torch.equal(live_per_row, every)
@@ -533,6 +534,9 @@ def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
     dc = util.DeviceCorpus.from_numpy(corpus, _dev())
     util.prepare_news_side(model.graph_encoder, dc, 1024)
     lib = _lib.lib()
+    if not hasattr(lib, "digat_set_staged_xattn"):
+        pytest.skip("the LDS-staged Eq. 8 variants are LAB-build material (-DDIGAT_LAB; DIGAT_HIP_LIB names such a build): "
+                    "measured slower in round 2, not in the product library")
     prev = lib.digat_set_staged_xattn(0)
     try:
         plain = util.score_rows(model, dc, 0, dc.rows, 1024)
@@ -542,9 +546,8 @@ def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
             lib.digat_set_staged_xattn(mode)
             got[mode, "grouped"] = util.score_rows(model, dc, 0, dc.rows, 1024)
             got[mode, "per row"] = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
-            skip_prev = lib.digat_set_live_row_skipping(0)
-            got[mode, "every row"] = util.score_rows(model, dc, 0, dc.rows, 1024)
-            lib.digat_set_live_row_skipping(skip_prev)
+            with model.graph_encoder.launch_options(live_rows=False):
+                got[mode, "every row"] = util.score_rows(model, dc, 0, dc.rows, 1024)
         hint = dict(model.graph_encoder.corpus_xattn_hint)
         model.graph_encoder.user_xattn_mode = "auto"
         model.graph_encoder.corpus_xattn_hint = {k: v for k, v in hint.items() if k != "user"}

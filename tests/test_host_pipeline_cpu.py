@@ -103,6 +103,46 @@ def test_two_rank_gloo_gather_equals_single_process():
     np.testing.assert_allclose(results[0][1], want_metrics, rtol=0, atol=0)
 
 
+class _FlagEncoder:
+    """What util.range_overflow_any_rank needs of an encoder: the flag and a tensor that says where it lives."""
+    def __init__(self, hit):
+        self.hit, self.topic_node_embedding = hit, torch.zeros(1)
+
+    def range_overflowed(self):
+        hit, self.hit = self.hit, False
+        return hit
+
+
+def _flag_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first = util.range_overflow_any_rank(_FlagEncoder(rank == 1), world)       # only rank 1's shard overflowed
+    second = util.range_overflow_any_rank(_FlagEncoder(False), world)
+    q.put((rank, first, second))
+    dist.destroy_process_group()
+
+
+def test_fp16x3_range_fallback_is_decided_for_all_ranks_together():
+    """A rank whose shard left fp16x3's range must not fall back alone (the all_gather would mix scores of two formats and the
+    ranks' caches would diverge): the flag is MAX-reduced over the group, every rank sees the same answer."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, False), (1, True, False)]
+    assert util.range_overflow_any_rank(_FlagEncoder(True)) and not util.range_overflow_any_rank(_FlagEncoder(False))
+
+
 def test_rank_file_bytes_equal_the_joined_rank_lines():
     """evaluate.rank_file_bytes (the library's host-side C formatter) against "\\n".join(rank_lines(...)): impressions without
     rows, one-row impressions, three-digit ranks, six-digit ids."""
