@@ -52,6 +52,11 @@ WORKLOADS = {
     "mind-large-default": dict(sag_neighbors=5, sag_hops=2, depth=3, category_num=18, news_num=161013, dropout=0.1,
                                label="MIND-large default shape: neighbors=5 hops=2 (N=26, U=68), d=400, graph_depth=3"),
 }
+# not a BASELINE config: the MIND-small default shapes with the OTHER adjacency regime real MIND also holds (full histories in 2-4
+# categories: 16 adjacency entries per user-graph node instead of 4.8, 79 % of the nodes live instead of 44 %)
+WORKLOADS["mind-small-heavy-history"] = dict(WORKLOADS["mind-small-default"], history_profile="heavy",
+                                             label="MIND-small default shapes, heavy histories: H = 50 for every user in 2-4 categories "
+                                                   "(N=10, U=67, d=400, graph_depth=3)")
 MIND_SMALL_DEV_ROWS = 2_740_000      # 73 152 impressions, ~2.74 M candidate rows
 MIND_SMALL_DEV_IMPRESSIONS = 73_152
 REFERENCE_BATCH = 1024               # the reference's dev batch: batch_size * 16 rows (main.py:42)
@@ -168,6 +173,30 @@ class Dist:
             import torch.distributed as dist
             dist.destroy_process_group()
 
+    def device_names(self):
+        """Every rank's device as it names itself (rank order): evidence of WHICH GPUs a multi-GPU line ran on."""
+        mine = f"{torch.cuda.get_device_name(self.device_index)} (cuda:{self.device_index}, pid {os.getpid()})"
+        if self.world == 1:
+            return [mine]
+        import torch.distributed as dist
+        names = [None] * self.world
+        dist.all_gather_object(names, mine)
+        return names
+
+
+class SoloView:
+    """One rank of a multi-rank run measuring by itself (the other ranks wait at the next fence): same device, no collectives."""
+
+    def __init__(self, D: "Dist"):
+        self.rank, self.world, self.dev, self.shared_gpu = D.rank, 1, D.dev, D.shared_gpu
+        self.device_index, self.backend, self.world_seen = D.device_index, None, 1
+
+    def fence(self):
+        torch.cuda.synchronize()
+
+    def reduce(self, values, op="sum"):
+        return [float(v) for v in values]
+
 
 def build_workload(name, args, D: Dist, impressions, trainable=False):
     """Corpus + model + device tables of one workload; the per-news caches (c_n0, layer-0 tables) are timed as setup."""
@@ -176,7 +205,8 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
     wl = WORKLOADS[name]
     news_num = args.news or wl["news_num"]
     spec = synthetic.SynthSpec(news_num=news_num, sag_neighbors=wl["sag_neighbors"], sag_hops=wl["sag_hops"],
-                               category_num=wl["category_num"], impressions=impressions, seed=D.rank)
+                               category_num=wl["category_num"], impressions=impressions, seed=D.rank,
+                               history_profile=wl.get("history_profile", "mind"))
     corpus = synthetic.make_corpus(spec)       # each rank owns its shard of the dev rows (weak scaling)
     N, H, C, d, L = spec.news_graph_size, spec.max_history_num, spec.category_num, spec.embedding_dim, wl["depth"]
     state = synthetic.make_state_dict(d, C, L, seed=0, bias_std=0.05)
@@ -230,7 +260,7 @@ class Scorer:
         self.per_row = args.per_row_users
         self.nbatches = max(1, W.dc.rows // self.B)
         self.imp_host = W.corpus.row_impression
-        self.lanes = util.batch_streams(D.dev, int(os.environ.get("DIGAT_BENCH_LANES", "3")))
+        self.lanes = util.batch_streams(D.dev, int(getattr(args, "lanes", 0) or os.environ.get("DIGAT_BENCH_LANES", "3")))
         self.nlanes = len(self.lanes)
         self.lane_scores = [torch.empty(self.B, dtype=torch.float32, device=D.dev) for _ in self.lanes]
         self.k, self.base, self.pipe, self.order = 0, 0, None, None
@@ -311,6 +341,7 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         torch.cuda.synchronize()
     # Setup, untimed: how many batches to keep in flight (util.batch_streams: 3 is best at the default shapes, 2 at the stress
     # shape and with bf16 P', Q — the optimum moves with the kernels' lengths, so it is measured, 2 x 30 steps per candidate)
+    t_tune = time.perf_counter()
     if "DIGAT_BENCH_LANES" not in os.environ and len(sc.lanes) >= 3:
         trials = {2: [], 3: []}
         for n in (3, 2, 3, 2, 3, 2):               # alternating rounds; the MEDIAN of each setting counts, and two batches in flight
@@ -327,6 +358,8 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
         sc.join()
         med = {n: sorted(v)[len(v) // 2] for n, v in trials.items()}
         sc.nlanes = 2 if med[2] < 0.98 * med[3] else 3
+    torch.cuda.synchronize()
+    untimed_s = {"prewarm": round(t_tune - t_pre, 3), "lane_tuning": round(time.perf_counter() - t_tune, 3)}
     for _ in range(warmup):
         sc.step()
     if gather_scores:                      # N > 1: the timed steps keep their scores for the closing all_gather
@@ -341,20 +374,24 @@ def run_inference(W, args, D: Dist, steps, warmup, with_profile=True, gather_sco
             _lib.lib().digat_profile_pause(0 if sampled else 1)
         profiled_steps += int(sampled)
         rows_done += sc.step()
-    gathered = None
+    gathered, gather_ms = None, None
     if gather_scores:
         # the multi-GPU driver's last act (util.compute_scores): every rank's block of scores to every rank, rank order
         sc.join()
+        torch.cuda.synchronize()                      # every score of this rank exists: what follows is the exchange alone
+        t_g0 = time.perf_counter()
         with torch.cuda.stream(sc.lanes[0]):
             local = torch.cat(sc.kept) if sc.kept else torch.empty(0, device=D.dev)
             counts = [int(v) for v in D.reduce([float(local.numel()) if r == D.rank else 0.0 for r in range(D.world)])]
             gathered = util.all_gather_scores(local.cpu() if D.shared_gpu else local, counts)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t_g0) * 1e3
         sc.kept = None
     D.fence()
     elapsed = time.perf_counter() - t0
     _lib.lib().digat_profile_marker(2, _lib.stream_ptr())       # ... and ends
     out = types.SimpleNamespace(elapsed=elapsed, rows_done=rows_done, profiled_steps=profiled_steps, revisited=sc.revisited,
-                                batches_in_flight=sc.nlanes,
+                                batches_in_flight=sc.nlanes, untimed_s=untimed_s, all_gather_ms=gather_ms,
                                 prof=None, prof_iso=None, live_fraction=None, iso_steps=0,
                                 gathered_rows=None if gathered is None else int(gathered.numel()))
     out.prof_all, out.all_steps = None, 0
@@ -537,6 +574,40 @@ def rooflines(W, run, args):
     return roof(dom), rx, kernel_ms, iso
 
 
+def roofline_step(W, run, ms_per_step):
+    """The whole step against the chip: executed matrix-core flops and compulsory HBM bytes of ONE step — every launch of the
+    untimed all-kinds pass (same streams, same batches in flight as the timed region) — each divided by its peak; the larger of
+    the two times is the floor of a step that overlapped everything perfectly, and frac = floor / measured ms_per_step."""
+    prof = getattr(run, "prof_all", None)
+    if not prof or not run.all_steps:
+        return None
+    enc = W.model.graph_encoder
+    f16 = hasattr(enc, "gemm_format") and enc.gemm_format() == 1
+    pm = enc.resolved_projection_mode() if hasattr(enc, "resolved_projection_mode") else "fp32"
+    nprod_proj = 3.0 if f16 else {"bf16x6": 6.0, "bf16x6-pq3": 4.0, "pq-bf16": 4.0, "pq-fp8": 4.0, "pq-bf16-x1": 8.0 / 3.0}.get(pm, 6.0)
+    nprod_lin = 3.0 if f16 else 6.0
+    steps = float(run.all_steps)
+    flops_alg = (prof["proj"]["work"] + prof["linear"]["work"]) / steps
+    flops_exec = (nprod_proj * prof["proj"]["work"] + nprod_lin * prof["linear"]["work"]) / steps
+    if pm == "fp32":
+        flops_exec, mfma_peak = flops_alg, MFMA_F32_PEAK_TFLOPS
+    else:
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS
+    gemm_bytes = (prof["proj"]["gemm_bytes"] + prof["linear"]["gemm_bytes"]) / steps
+    other_bytes = sum(prof[k]["work"] for k in ("xattn", "pool", "topic", "glue", "agg")) / steps
+    t_mfma = flops_exec / (mfma_peak * 1e12) * 1e3
+    t_hbm = (gemm_bytes + other_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
+    floor = max(t_mfma, t_hbm)
+    return {"executed_mfma_flops_per_step": flops_exec, "algorithmic_flops_per_step": flops_alg, "mfma_peak_tflops": mfma_peak,
+            "mfma_floor_ms": t_mfma, "compulsory_hbm_bytes_per_step": gemm_bytes + other_bytes,
+            "hbm_bytes_of_the_gemms": gemm_bytes, "hbm_bytes_of_eq8_pooling_glue": other_bytes, "hbm_peak_gbs": HBM_PEAK_GBS,
+            "hbm_floor_ms": t_hbm, "bound": "hbm" if t_hbm >= t_mfma else "mfma", "floor_ms": floor, "ms_per_step": ms_per_step,
+            "frac": floor / ms_per_step if ms_per_step > 0 else None,
+            "note": "floor = max(executed matrix-core flops / dense 16-bit peak, compulsory HBM bytes / 8 TB/s) of one step; GEMM bytes = "
+                    "operand rows in + result rows out (+ epilogue row operands), weights not counted (L2-resident); Eq. 8 / pooling / glue "
+                    "bytes as in roofline_xattn; the guide's achievable HBM rate (6.3 TB/s) would raise hbm_floor_ms by 1.27x"}
+
+
 def cpu_baseline_and_auc(W, args, cpu_rows, cpu_seconds, report_baseline):
     """The oracle (unfused reference algorithm, torch-CPU fp32) on whole impressions of the same dev rows: the reported,
     non-target CPU baseline, and the scores the GPU path is held to (AUC / MRR / nDCG within 1e-4)."""
@@ -604,7 +675,7 @@ def cpu_baseline_and_auc(W, args, cpu_rows, cpu_seconds, report_baseline):
     return baseline, auc_match, (cpu_scores, n_rows)
 
 
-def auc_match_trained(args, D):
+def auc_match_trained(args, D, projection=None):
     """"AUC-matched" on a model that ranks: the trained weights of tests/golden/trained_planted_state.npz on the held-out dev split
     of the planted-signal corpus (2 000 impressions, ~74 k rows), scored through this library, against the scores / metrics the
     IMPORTED REFERENCE produced for the same inputs in the build container (tests/golden/devset_trained_2k.npz: AUC 0.644, logits
@@ -626,7 +697,7 @@ def auc_match_trained(args, D):
     model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
     model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(D.dev).eval()
-    model.graph_encoder.projection_mode = args.projection
+    model.graph_encoder.projection_mode = projection or args.projection
     dc = util.DeviceCorpus.from_numpy(corpus, D.dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -792,6 +863,20 @@ def main():
     # extra_workloads["mind-large-default"]) — the N = 1 headline is the MIND-small workload, BASELINE configs[1]
     per_rank = D.reduce([(run.rows_done / run.elapsed) if r == D.rank else 0.0 for r in range(D.world)])
     lanes_by_rank = D.reduce([float(run.batches_in_flight) if r == D.rank else 0.0 for r in range(D.world)])
+    gather_ms_by_rank = D.reduce([float(run.all_gather_ms or 0.0) if r == D.rank else 0.0 for r in range(D.world)])
+    devices = D.device_names()
+    # N > 1 scores the MIND-large workload (BASELINE configs[3]) while the N = 1 headline is MIND-small (configs[1]): dividing one by
+    # the other is not a scaling efficiency.  So the N > 1 line carries its OWN one-GPU reference: after the timed region rank 0
+    # scores the same workload, same steps, alone (the other ranks wait at the fence below, their GPUs idle).
+    n1_same = None
+    if D.world > 1:
+        D.fence()
+        if D.rank == 0:
+            rs = run_inference(W, args, SoloView(D), args.steps, args.warmup, with_profile=False, gather_scores=False)
+            n1_same = {"value": (rs.rows_done / W.mean_cand) / rs.elapsed, "unit": "impressions/s", "ms_per_step": rs.elapsed / args.steps * 1e3,
+                       "steps": args.steps, "batches_in_flight": rs.batches_in_flight,
+                       "what": "rank 0 alone on the same workload and shard, right after the timed region (other ranks idle at a barrier)"}
+        D.fence()
     if D.rank != 0:
         D.close()
         return
@@ -823,24 +908,58 @@ def main():
                 "ms_per_step": r1k.elapsed / n1k * 1e3, "rows_per_step": REFERENCE_BATCH, "steps": n1k,
                 "batches_in_flight": r1k.batches_in_flight,
                 "what": "util.score_rows(..., launch_rows=1024): every reference dev batch its own pass through the encoder"}
+        if True:
+            # What INTEGRATION.md section 1's two-line swap delivers to the REFERENCE's own driver (util.py:51-69): Model.inference on
+            # expanded per-row user tensors, one 1024-row dev batch per call, no grouping, no per-news layer-0 / query tables, one
+            # stream — and the same calls issued over three alternating streams (a driver change of a few lines)
+            import copy
+            ad = copy.copy(args)
+            ad.batch, ad.per_row_users = REFERENCE_BATCH, True
+            nd = args.extra_steps * 6
+            drop = {}
+            for lanes, tag in ((1, "one_stream"), (3, "three_streams")):
+                ad.lanes = lanes
+                os.environ["DIGAT_BENCH_LANES"] = str(lanes)      # no lane tuning inside run_inference: the lane count IS the variant
+                try:
+                    rd = run_inference(W, ad, D, nd, 5, with_profile=False)
+                finally:
+                    del os.environ["DIGAT_BENCH_LANES"]
+                drop[tag] = {"value": (rd.rows_done / W.mean_cand) / rd.elapsed, "ms_per_step": rd.elapsed / nd * 1e3,
+                             "rows_per_s": rd.rows_done / rd.elapsed, "steps": nd}
+            extra["mind-small-default/drop-in"] = {
+                "value": drop["one_stream"]["value"], "unit": "impressions/s", "rows_per_step": REFERENCE_BATCH, **drop,
+                "what": "the reference's driver loop unchanged except graphEncoders.DIGAT -> digat_amd.graphEncoders.DIGAT (INTEGRATION.md "
+                        "section 1): Model.inference(expanded [1024, ...] user tensors, cached c_n0) per dev batch — digat_encoder_fwd, no "
+                        "row_group, no per-news tables; inputs gathered on the device (the reference's DataLoader is host-side and not part "
+                        "of this number)"}
         if args.projection in ("auto", "bf16x6") and cpu_sample is not None:
-            # BASELINE configs[4], inference half: the same workload with P', Q of Eq. 8 stored in bf16 (projection_mode
-            # "pq-bf16"); metric drift on the rows of the CPU sample against the fp32 oracle
+            # BASELINE configs[4], inference half: the same workload with P', Q of Eq. 8 stored in bf16 ("pq-bf16") and as
+            # block-scaled e4m3 ("pq-fp8").  Drift is measured where "AUC-matched" means something — the trained model's 2 000
+            # impressions against the imported reference's own metrics (tests/golden/devset_trained_2k.npz) — and, for reference,
+            # on the random-click rows of the CPU sample against the fp32 oracle (41 impressions: a noisy yardstick)
             from digat_amd import evaluate, util
-            W.model.graph_encoder.projection_mode = "pq-bf16"
-            r4 = run_inference(W, args, D, args.extra_steps, 3, with_profile=False)
             cpu_scores, n_rows = cpu_sample
-            sc = util.score_rows(W.model, W.dc, 0, n_rows, args.batch).cpu().numpy()
             lab, ri = W.corpus.row_label[:n_rows], W.corpus.row_impression[:n_rows]
-            mg = evaluate.scoring(lab, evaluate.impression_ranks(sc, ri), ri)
             mc = evaluate.scoring(lab, evaluate.impression_ranks(cpu_scores, ri), ri)
-            extra["mind-small-default/pq-bf16"] = {
-                "value": (r4.rows_done / W.mean_cand) / r4.elapsed, "unit": "impressions/s", "rows_per_s": r4.rows_done / r4.elapsed,
-                "ms_per_step": r4.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps, "batches_in_flight": r4.batches_in_flight,
-                "dtype": "f32 with P', Q of Eq. 8 (user graph, layers >= 1) in bf16",
-                "max_abs_metric_diff_vs_fp32_oracle": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
-                "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
-                "rows_compared": int(n_rows)}
+            for pm_low, what in (("pq-bf16", "bf16"), ("pq-fp8", "block-scaled OCP e4m3 (one fp32 scale per row and 80-channel strip)")):
+                W.model.graph_encoder.projection_mode = pm_low
+                r4 = run_inference(W, args, D, args.extra_steps, 3, with_profile=False)
+                sc = util.score_rows(W.model, W.dc, 0, n_rows, args.batch).cpu().numpy()
+                mg = evaluate.scoring(lab, evaluate.impression_ranks(sc, ri), ri)
+                tr4 = auc_match_trained(args, D, projection=pm_low)
+                extra["mind-small-default/" + pm_low] = {
+                    "value": (r4.rows_done / W.mean_cand) / r4.elapsed, "unit": "impressions/s", "rows_per_s": r4.rows_done / r4.elapsed,
+                    "ms_per_step": r4.elapsed / args.extra_steps * 1e3, "steps": args.extra_steps, "batches_in_flight": r4.batches_in_flight,
+                    "dtype": "f32 with P', Q of Eq. 8 (user graph, layers >= 1) stored as " + what,
+                    "max_abs_metric_diff_vs_reference_trained_2k": None if tr4 is None else tr4["max_abs_metric_diff"],
+                    "metric_diffs_vs_reference_trained_2k": None if tr4 is None else
+                    [round(abs(a - b), 7) for a, b in zip(tr4["gpu"], tr4["reference"])],
+                    "ranks_equal_fraction_trained_2k": None if tr4 is None else tr4["ranks_equal_fraction"],
+                    "within_1e-4": None if tr4 is None else bool(tr4["max_abs_metric_diff"] <= 1e-4),
+                    "max_abs_metric_diff_vs_fp32_oracle_random_clicks": float(np.max(np.abs(np.array(mg) - np.array(mc)))),
+                    "mean_rel_score_diff_vs_fp32_oracle": float(np.mean(np.abs(sc - cpu_scores) / (np.abs(cpu_scores) + 1e-3))),
+                    "rows_compared_random_clicks": int(n_rows),
+                    "projection_gemm_result_bytes_per_row": {"pq-bf16": 4 * W.d + 2 * 2 * W.d, "pq-fp8": 4 * W.d + 2 * 448}[pm_low] if W.d == 400 else None}
             # the same workload under the OTHER operand format of the matrix-core GEMMs: "bf16x6" (three bf16 pieces, six products, no
             # range limit) when the headline ran "fp16x3" (two fp16 pieces, three products; what "auto" picks for weights below 32)
             W.model.graph_encoder.projection_mode = args.projection
@@ -859,16 +978,33 @@ def main():
                 "rows_compared": int(n_rows)}
             W.model.graph_encoder.projection_mode = args.projection
             util.prepare_news_side(W.model.graph_encoder, W.dc, args.batch)
-        for other in ("mind-small-stress", "mind-large-default"):
+        for other in ("mind-small-stress", "mind-large-default", "mind-small-heavy-history"):
             W2 = build_workload(other, args, D, 4096)
             r2 = run_inference(W2, args, D, args.extra_steps, 3, with_profile=True)
             roof2, roofx2, kms2, kiso2 = rooflines(W2, r2, args)
             extra[other] = {"value": (r2.rows_done / W2.mean_cand) / r2.elapsed, "unit": "impressions/s",
                             "rows_per_s": r2.rows_done / r2.elapsed, "ms_per_step": r2.elapsed / args.extra_steps * 1e3,
                             "steps": args.extra_steps, "batches_in_flight": r2.batches_in_flight, "setup_ms": round(W2.setup_ms, 1),
-                            "roofline": roof2, "roofline_xattn": roofx2, "kernel_ms_per_step": kms2,
+                            "roofline": roof2, "roofline_xattn": roofx2, "roofline_step": roofline_step(W2, r2, r2.elapsed / args.extra_steps * 1e3),
+                            "kernel_ms_per_step": kms2,
                             "kernel_ms_per_step_single_stream": kiso2, "live_row_fraction": r2.live_fraction,
                             "config": workload_config(W2, args, D)}
+            if other == "mind-small-heavy-history":
+                # the adjacency regime decides the Eq. 8 variant: say which one ran, time the other one too, and hold the scores of a
+                # ~1 500-row sample to the fp32 oracle (the same criterion as the headline's auc_match)
+                enc2 = W2.model.graph_encoder
+                ug = W2.corpus.user_graph
+                extra[other]["adjacency_entries_per_node"] = round(float(ug.sum()) / (ug.shape[0] * ug.shape[1]), 2)
+                chosen = enc2.resolved_xattn_mode("user")
+                alt = "dense" if chosen == "sparse" else "sparse"
+                enc2.user_xattn_mode = alt
+                r2b = run_inference(W2, args, D, args.extra_steps, 3, with_profile=False)
+                enc2.user_xattn_mode = "auto"
+                extra[other]["user_graph_eq8_variants"] = {chosen + " (chosen)": round(r2.elapsed / args.extra_steps * 1e3, 4),
+                                                           alt: round(r2b.elapsed / args.extra_steps * 1e3, 4), "unit": "ms per step"}
+                if args.cpu_rows > 0:
+                    _, am2, _ = cpu_baseline_and_auc(W2, args, min(args.cpu_rows, 1536), min(args.cpu_seconds, 20.0), report_baseline=False)
+                    extra[other]["auc_match"] = am2
             del W2, r2
             torch.cuda.empty_cache()
         # the DDP training step of the same shapes (trainer.py:71-105; `--mode train` times it alone): forward, backward, clip, Adam
@@ -924,12 +1060,22 @@ def main():
         # measurement before the warm-up unless DIGAT_BENCH_LANES says
         "batches_in_flight": run.batches_in_flight if D.world == 1 else [int(v) for v in lanes_by_rank],
         "per_rank_impressions_per_s": None if D.world == 1 else [round(v / mean_cand, 1) for v in per_rank],
+        # N > 1 only: the one-GPU rate of THIS workload measured in this run, and value / (N x that); the closing all_gather of
+        # the scores (inside the timed region) per rank; the devices the ranks ran on
+        "n1_same_workload": n1_same,
+        "scaling_efficiency": None if n1_same is None else ((rows_total / mean_cand) / elapsed) / (D.world * n1_same["value"]),
+        "all_gather_ms_by_rank": None if D.world == 1 else [round(v, 3) for v in gather_ms_by_rank],
+        "devices": devices,
         # prepare_news_side (SA gather, c_n0, the layer-0 tables): once per dev run and weight version, outside the timed region
         "setup_ms": round(W.setup_ms, 1),
+        # untimed, before the warm-up: clocks out of idle (pre-warm) and the choice between two and three launch sets in flight
+        "untimed_seconds_before_the_timed_region": run.untimed_s,
         "setup_ms_per_step_amortised": {"over_this_corpus": round(W.setup_ms / nb_corpus, 4),
                                         "over_mind_small_dev": round(W.setup_ms / (MIND_SMALL_DEV_ROWS / args.batch), 4)},
         "roofline": roof_dom,
         "roofline_xattn": roof_x,
+        # the whole step against the chip: executed matrix-core flops and compulsory HBM bytes, each / peak, vs ms_per_step
+        "roofline_step": roofline_step(W, run, elapsed / args.steps * 1e3),
         "kernel_ms_per_step": kernel_ms,
         "kernel_ms_per_step_single_stream": kernel_iso,
         # rows projected / rows nominal over the row-list launches (user-graph layers >= 1 and featureAffine): the encoder

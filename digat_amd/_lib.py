@@ -158,6 +158,7 @@ _SIGNATURES = {
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
+    "digat_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "digat_profile_marker": (C.c_int, [C.c_int, _f]),
 }
 _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
@@ -233,7 +234,9 @@ def profile_stop():
     n = len(KERNEL_KINDS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
     check(lib().digat_profile_stop(ms, work, cnt), "digat_profile_stop")
-    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, k in enumerate(KERNEL_KINDS)}
+    gb = (C.c_double * n)()
+    check(lib().digat_profile_gemm_bytes(gb), "digat_profile_gemm_bytes")
+    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i], "gemm_bytes": gb[i]} for i, k in enumerate(KERNEL_KINDS)}
 
 
 def split_buffer(nbytes: int, device: torch.device) -> torch.Tensor:

@@ -58,14 +58,16 @@ static struct {
     unsigned long long* rows_dev;      // [kinds] row-list GEMM launches add the rows they actually processed (device counters)
     double flops_per_row[16]; double rows_nominal[16];
     unsigned kind_mask;                // only launches of these kinds are bracketed (digat_profile_set_kinds)
-} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}, ~0u};
+    double* bytes;                     // MFMA kinds: the operand + result bytes of the launch (digat_profile_gemm_bytes)
+    double bytes_per_row[16];
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}, ~0u, nullptr, {0.0}};
 
 struct ProfScope {
     hipStream_t st; int slot;
-    ProfScope(int kind, double work, hipStream_t s) : st(s), slot(-1) {
+    ProfScope(int kind, double work, hipStream_t s, double bytes = 0.0) : st(s), slot(-1) {
         if (g_prof.enabled && ((g_prof.kind_mask >> kind) & 1u) && g_prof.used < g_prof.cap) {
             slot = g_prof.used++;
-            g_prof.kind[slot] = kind; g_prof.work[slot] = work;
+            g_prof.kind[slot] = kind; g_prof.work[slot] = work; g_prof.bytes[slot] = bytes;
             (void)hipEventRecord(g_prof.ev[2 * slot], st);
         }
     }
@@ -1188,6 +1190,12 @@ int digat_news_project0(const digat_params* p, const float* Xn, float* hpq, int 
 
 static double g_prof_last_live_fraction = -1.0;
 double digat_profile_live_row_fraction(void) { return g_prof_last_live_fraction; }
+static double g_prof_last_gemm_bytes[DIGAT_KERNEL_KINDS] = {0.0};
+int digat_profile_gemm_bytes(double* bytes_per_kind) {
+    if (!bytes_per_kind) return DIGAT_ERR_ARG;
+    for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k) bytes_per_kind[k] = g_prof_last_gemm_bytes[k];
+    return DIGAT_OK;
+}
 
 // recording costs two hipEventRecord calls per launch on the host: a caller that wants per-kernel times over a long
 // region without slowing it down samples it — pause(1) ... pause(0) around the steps it does not want recorded
@@ -1221,12 +1229,13 @@ int digat_profile_start(int max_launches) {
     g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_launches);
     g_prof.kind = (int*)malloc(sizeof(int) * max_launches);
     g_prof.work = (double*)malloc(sizeof(double) * max_launches);
-    if (!g_prof.ev || !g_prof.kind || !g_prof.work) return DIGAT_ERR_ARG;
+    g_prof.bytes = (double*)malloc(sizeof(double) * max_launches);
+    if (!g_prof.ev || !g_prof.kind || !g_prof.work || !g_prof.bytes) return DIGAT_ERR_ARG;
     for (int i = 0; i < 2 * max_launches; ++i)
         if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return DIGAT_ERR_LAUNCH;
     if (hipMalloc((void**)&g_prof.rows_dev, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(g_prof.rows_dev, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return DIGAT_ERR_LAUNCH;
-    for (int k = 0; k < 16; ++k) { g_prof.flops_per_row[k] = 0.0; g_prof.rows_nominal[k] = 0.0; }
+    for (int k = 0; k < 16; ++k) { g_prof.flops_per_row[k] = 0.0; g_prof.rows_nominal[k] = 0.0; g_prof.bytes_per_row[k] = 0.0; }
     g_prof.cap = max_launches; g_prof.used = 0; g_prof.enabled = 1;
     return DIGAT_OK;
 }
@@ -1238,6 +1247,7 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         if (ms_per_kind) ms_per_kind[k] = 0;
         if (work_per_kind) work_per_kind[k] = 0;
         if (launches_per_kind) launches_per_kind[k] = 0;
+        g_prof_last_gemm_bytes[k] = 0.0;
     }
     int rc = DIGAT_OK;
     for (int i = 0; i < g_prof.used; ++i) {
@@ -1248,13 +1258,16 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         if (ms_per_kind) ms_per_kind[k] += ms;
         if (work_per_kind) work_per_kind[k] += g_prof.work[i];
         if (launches_per_kind) launches_per_kind[k] += 1;
+        g_prof_last_gemm_bytes[k] += g_prof.bytes[i];
     }
     g_prof_last_live_fraction = -1.0;
     if (g_prof.rows_dev) {
         unsigned long long rows[16];
         if (hipMemcpy(rows, g_prof.rows_dev, sizeof(rows), hipMemcpyDeviceToHost) == hipSuccess) {
-            for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k)
+            for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k) {
                 if (work_per_kind) work_per_kind[k] += (double)rows[k] * g_prof.flops_per_row[k];
+                if (k == DIGAT_KERNEL_PROJ || k == DIGAT_KERNEL_LINEAR) g_prof_last_gemm_bytes[k] += (double)rows[k] * g_prof.bytes_per_row[k];
+            }
             if (g_prof.rows_nominal[DIGAT_KERNEL_PROJ] > 0)
                 g_prof_last_live_fraction = (double)rows[DIGAT_KERNEL_PROJ] / g_prof.rows_nominal[DIGAT_KERNEL_PROJ];
         }
@@ -1262,8 +1275,8 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         g_prof.rows_dev = nullptr;
     }
     for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-    free(g_prof.ev); free(g_prof.kind); free(g_prof.work);
-    g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.cap = g_prof.used = 0;
+    free(g_prof.ev); free(g_prof.kind); free(g_prof.work); free(g_prof.bytes);
+    g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.bytes = nullptr; g_prof.cap = g_prof.used = 0;
     return rc;
 }
 

@@ -573,6 +573,10 @@ int digat_profile_pause(int paused);   /* between start and stop: 1 = launches a
  * layers >= 1), or -1 if there was none */
 double digat_profile_live_row_fraction(void);
 int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches_per_kind);
+/* After digat_profile_stop: the compulsory HBM bytes (operand rows in, result rows out, epilogue row operands; weights not
+ * counted) of the recorded launches of the two MFMA kinds, DIGAT_KERNEL_PROJ and DIGAT_KERNEL_LINEAR, whose `work` is flops —
+ * for a whole-step roofline (bench.py: roofline_step).  DIGAT_KERNEL_KINDS entries; the byte-priced kinds read 0 here. */
+int digat_profile_gemm_bytes(double* bytes_per_kind);
 
 #ifdef __cplusplus
 }
