@@ -505,7 +505,7 @@ struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 // Nothing below is mutable: live-row lists and the side stream are chosen PER CALL through digat_params.flags
 // (DIGAT_PARAMS_NO_LIVE_ROWS, DIGAT_PARAMS_SIDE_STREAM_OFF / _ON), so two host threads with different settings cannot flip each
 // other's (round 3 had process-wide setters for them).
-static const int g_sparse_per_node = LAB_ENV("DIGAT_SPARSE_PER_NODE", 12);
+static const int g_sparse_per_node = LAB_ENV("DIGAT_SPARSE_PER_NODE", 20);
 // 0 = never, 1 = always, 2 = by pass size (default): below 2 048 rows — there the news kernels are a few waves of workgroups each;
 // from 2 048 rows up every kernel fills the chip by itself and the second stream only makes launches share it (4 096 rows,
 // three passes in flight: 3.21 vs 3.28 ms per pass; stress 16.4 vs 16.8, MIND-large shape 4.52 vs 4.65).  DIGAT_SINGLE_STREAM=1 / 0

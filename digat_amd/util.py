@@ -23,7 +23,8 @@ import torch
 from . import evaluate
 
 
-SPARSE_ENTRIES_PER_NODE = 12        # the library's own threshold for DIGAT_XATTN_AUTO (digat_kernels.hip)
+SPARSE_ENTRIES_PER_NODE = 20        # the library's own threshold for DIGAT_XATTN_AUTO (digat_kernels.hip); measured at 15.7 entries per node
+                                    # (heavy histories, bench.py): sparse 5.34 vs dense 6.11 ms per 4096-row step; break-even extrapolates to ~21
 
 
 @dataclass

@@ -145,7 +145,7 @@ int digat_topic_pool_fwd(const float* Xu, const float* kq, const int64_t* cat_id
 /* Eq. 8 of the USER graph inside the encoder entry points (digat_params.flags, bits 0-1).  MIND user graphs hold ~4 entries
  * per adjacency row; xattn_sparse_kernel visits only those (score, softmax and aggregation in one launch), the dense pair
  * (tile score kernel + MFMA aggregation) streams whole rows.  AUTO: both are launched and a device-side count of the
- * adjacency entries (<= 12 per node on average: sparse) lets one of them return at its first instruction — no host
+ * adjacency entries (<= 20 per node on average: sparse) lets one of them return at its first instruction — no host
  * synchronisation; results differ between the two only by fp32 summation order.  Callers that know their graphs choose. */
 enum { DIGAT_XATTN_AUTO = 0, DIGAT_XATTN_DENSE = 1, DIGAT_XATTN_SPARSE = 2 };
 /* digat_params.flags bit 2 (folded inference path, bf16x6 projections only): the P and Q projections of Eq. 8 — which only
