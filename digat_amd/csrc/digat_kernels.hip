@@ -552,7 +552,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
-                              const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
+                              void* chunk_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
                               const int64_t* news_index, int64_t news_rows, const float* c_n_src) {
     // c_n_src: where the news context stands BEFORE layer 0 — c_n itself, or (depth >= 1, context given) the caller's c_n0, read
     // in place by the two consumers that precede the first update instead of being copied into c_n first
@@ -639,6 +639,15 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     const int *pend_rowidx = nullptr, *pend_nrows = nullptr, *pend_bidx = nullptr, *pend_nb = nullptr, *pend_hlast = nullptr;
 
     uint8_t* pend_flags = nullptr;
+    // layer 0 of grouped rows on the chunk kernel (R rows of an impression per wave: xattn_sparse_l0_kernel): its list — the live
+    // centres of the rows that lead a chunk — is made with the other two
+    static const int l0_chunks_on = LAB_ENV("DIGAT_L0_CHUNKS", 1);
+    const bool l0_chunked = l0_chunks_on && chunk_ws && row_group && Xg0 && want_live && g_l0_live_on && !use_staged &&
+                            sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 128 && U <= 128;
+    int* const l0_gs = (int*)chunk_ws;
+    int* const l0_off = l0_gs + align_up((size_t)B + 64, 64);
+    uint8_t* const l0_lead = (uint8_t*)(l0_off + align_up((size_t)B + 64, 64));
+    int* const l0_idx = (int*)(l0_lead + align_up((size_t)B, 256));
     auto find_live_rows = [&](hipStream_t sq) -> int {
         int* cnt = live_ws;
         int* off = cnt + align_up((size_t)B, 64);
@@ -652,6 +661,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         uint8_t* flags1 = (uint8_t*)(hlast + align_up((size_t)B, 64));
         uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
+        if (l0_chunked) {
+            hipLaunchKernelGGL(sparse_l0_chunks_kernel, dim3(1), dim3(1024), 0, sq, row_group, B, G, SPARSE_L0_ROWS, l0_gs, l0_lead);
+            DIGAT_CHECK_LAUNCH();
+        }
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
                            flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2);
         DIGAT_CHECK_LAUNCH();
@@ -661,11 +674,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             sparse_flag = flag;
         }
         // node list and bucket list: both scans in one launch, both lists in one launch
-        const ScanPair sp{{cnt, cnt2}, {off, off2}};
-        hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(2), dim3(1024), 0, sq, sp, B);
+        const ScanPair sp{{cnt, cnt2, cnt}, {off, off2, l0_off}, {nullptr, nullptr, l0_lead}};
+        hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(l0_chunked ? 3 : 2), dim3(1024), 0, sq, sp, B);
         DIGAT_CHECK_LAUNCH();
-        const ListPair lp{{flags1, flags2}, {off, off2}, {U, C1}, {idx, idx2}};
-        hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, 2), dim3(256), 0, sq, lp, B);
+        const ListPair lp{{flags1, flags2, flags1}, {off, off2, l0_off}, {U, C1, U}, {idx, idx2, l0_idx}, {nullptr, nullptr, l0_lead}};
+        hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, l0_chunked ? 3 : 2), dim3(256), 0, sq, lp, B);
         DIGAT_CHECK_LAUNCH();
         pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1; pend_hlast = hlast;
         return DIGAT_OK;
@@ -844,6 +857,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                     sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, xu0_grouped ? 1 : 0,
                                     (!l0_live && xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
                                     l0_live ? rowidx : nullptr, l0_live ? nrows_dev : nullptr, G, nullptr, 0, 0};
+                if (l0_chunked && l0_live && sparse_l0_ok(sg)) {
+                    // R rows of an impression per wave: every neighbour row fetched serves R rows (xattn_sparse_l0_kernel; same bits)
+                    rc = launch_sparse_l0(sg, l0_lead, l0_idx, l0_off + B, G, st);
+                } else
                 rc = use_staged ? launch_staged(sg, plan, 0, 0, st) : launch_sparse(sg, st);
             }
             if (!rc && !(sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 256)) {
@@ -924,6 +941,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     return DIGAT_OK;
 }
 
+// layer 0 of grouped rows (xattn_sparse_l0_kernel): group starts [B + 64] int, rows led by each row [B] bytes, offsets [B + 64] int
+// and list [B U] int of the live centres of the chunk-leading rows
+static size_t l0_chunk_bytes(int B, int U) {
+    return 2 * align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B, 256) + align_up((size_t)B * U * 4, 256);
+}
+
 size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
     (void)depth;
     const int U = H + C;
@@ -939,6 +962,7 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     // + adjacency entries per row and the sparse / dense decision (int)
     tot += align_up((4 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
                      + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256), 256);
+    tot += l0_chunk_bytes(B, U);                          // layer 0 of grouped rows: group starts + rows led by each row (xattn_sparse_l0_kernel)
     tot += plan_bytes(B, U);                             // the staged Eq. 8 kernel's plan of the batch (digat_staged.inc)
     return tot;
 }
@@ -989,6 +1013,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     void* xws_news = ws + 5 * sb;
     int* live_ws = (int*)((char*)xws_news + digat_xattn_workspace_bytes(B, N, d));
     void* plan_ws = (char*)workspace + digat_encoder_workspace_bytes(B, N, H, C, d, L) - plan_bytes(B, U);
+    void* chunk_ws = (char*)plan_ws - l0_chunk_bytes(B, U);
 
     int rc;
     const bool folded = p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W;
@@ -1022,7 +1047,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, Au_g, cm_g, ci_g,
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, Au_g, cm_g, ci_g,
                                   c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
