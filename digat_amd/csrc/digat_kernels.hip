@@ -129,6 +129,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
     }
 }
 
+constexpr int TWIN_R = 4;          // centres with equal adjacency rows served by one wave (user_live_flags_kernel, xattn_sparse_twin_kernel)
 #include "digat_gemm.inc"
 #include "digat_xattn.inc"
 #include "digat_context.inc"
@@ -184,6 +185,8 @@ int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, co
     return launch_xattn_pairwise(Pr, Q, h, X, a, A, out, alpha, B, n, d, (hipStream_t)stream);
 }
 
+struct TwinLists { const unsigned* word; const int* list; const int* count; };     // user_live_flags_kernel's twins (see there)
+
 // Eq. 8 layer with K3 (r = ctx F3^T + b3) already computed; `r_given` may live anywhere
 static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const float* W, const float* bW, const float* F1, const float* F2, const float* a,
@@ -191,7 +194,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
                       int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0,
-                      int gemm_format = 0, unsigned* range_flag = nullptr) {
+                      int gemm_format = 0, unsigned* range_flag = nullptr, const TwinLists* tw = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -226,6 +229,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
                       listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq8 ? 2 : (pq16 ? 1 : 0), plan ? 0 : centre_limit};
         sg.ld8 = pq8 ? ld8 : 0;
+        if (tw && listed && live && !plan) { sg.twin = tw->word; sg.twlist = tw->list; sg.twcount = tw->count; }
         // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
         const int rcs = plan ? launch_staged(sg, *plan, listed && live ? 1 : 0, plan_slot, st) : launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
@@ -648,6 +652,15 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     int* const l0_off = l0_gs + align_up((size_t)B + 64, 64);
     uint8_t* const l0_lead = (uint8_t*)(l0_off + align_up((size_t)B + 64, 64));
     int* const l0_idx = (int*)(l0_lead + align_up((size_t)B, 256));
+    // twins: centres of a graph with equal adjacency rows, served together in layers >= 1 (xattn_sparse_twin_kernel)
+    static const int twins_on = LAB_ENV("DIGAT_SPARSE_TWINS", 1);
+    const bool twins = twins_on && chunk_ws && want_live && !use_staged && sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 128 && U <= 128 && L > 1;
+    unsigned* const tw_word = (unsigned*)((char*)l0_idx + align_up((size_t)B * U * 4, 256));
+    int* const tw_list = (int*)((char*)tw_word + align_up((size_t)B * U * 4, 256));
+    uint8_t* const tw_flags = (uint8_t*)tw_list + align_up((size_t)B * U * 4, 256);
+    int* const tw_cnt = (int*)(tw_flags + align_up((size_t)B * U, 256));
+    int* const tw_off = tw_cnt + align_up((size_t)B + 64, 64);
+    TwinLists tw_pub{nullptr, nullptr, nullptr};
     auto find_live_rows = [&](hipStream_t sq) -> int {
         int* cnt = live_ws;
         int* off = cnt + align_up((size_t)B, 64);
@@ -666,7 +679,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             DIGAT_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2);
+                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2,
+                           twins ? tw_word : (unsigned*)nullptr, twins ? tw_flags : (uint8_t*)nullptr, twins ? tw_cnt : (int*)nullptr);
         DIGAT_CHECK_LAUNCH();
         if (sparse_mode == DIGAT_XATTN_AUTO) {
             hipLaunchKernelGGL(sparse_decide_kernel, dim3(1), dim3(1024), 0, sq, (const int*)entries, B, U, g_sparse_per_node, flag);
@@ -674,11 +688,23 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             sparse_flag = flag;
         }
         // node list and bucket list: both scans in one launch, both lists in one launch
-        const ScanPair sp{{cnt, cnt2, cnt}, {off, off2, l0_off}, {nullptr, nullptr, l0_lead}};
-        hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(l0_chunked ? 3 : 2), dim3(1024), 0, sq, sp, B);
+        // up to four lists in the two launches: live nodes, live buckets, [layer-0 chunk leads | twin leads] as wanted
+        ScanPair sp{{cnt, cnt2, nullptr, nullptr}, {off, off2, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        ListPair lp{{flags1, flags2, nullptr, nullptr}, {off, off2, nullptr, nullptr}, {U, C1, U, U}, {idx, idx2, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        int jobs = 2;
+        if (l0_chunked) {
+            sp.cnt[jobs] = cnt; sp.off[jobs] = l0_off; sp.rowmask[jobs] = l0_lead;
+            lp.flags[jobs] = flags1; lp.off[jobs] = l0_off; lp.out[jobs] = l0_idx; lp.rowmask[jobs] = l0_lead;
+            ++jobs;
+        }
+        if (twins) {
+            sp.cnt[jobs] = tw_cnt; sp.off[jobs] = tw_off;
+            lp.flags[jobs] = tw_flags; lp.off[jobs] = tw_off; lp.out[jobs] = tw_list;
+            ++jobs;
+        }
+        hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(jobs), dim3(1024), 0, sq, sp, B);
         DIGAT_CHECK_LAUNCH();
-        const ListPair lp{{flags1, flags2, flags1}, {off, off2, l0_off}, {U, C1, U}, {idx, idx2, l0_idx}, {nullptr, nullptr, l0_lead}};
-        hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, l0_chunked ? 3 : 2), dim3(256), 0, sq, lp, B);
+        hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, jobs), dim3(256), 0, sq, lp, B);
         DIGAT_CHECK_LAUNCH();
         pend_rowidx = idx; pend_nrows = off + B; pend_bidx = idx2; pend_nb = off2 + B; pend_flags = flags1; pend_hlast = hlast;
         return DIGAT_OK;
@@ -693,6 +719,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     auto publish_live_rows = [&]() {
         rowidx = pend_rowidx; nrows_dev = pend_nrows; bucket_idx = pend_bidx; nbuckets_dev = pend_nb; live_flags = pend_flags;
         hist_last = pend_hlast;
+        if (twins) tw_pub = TwinLists{tw_word, tw_list, tw_off + B};
     };
     // side stream: by pass size unless the caller says (flags): never / always
     int side_mode = (p->flags & DIGAT_PARAMS_SIDE_STREAM_OFF) ? 0 : ((p->flags & DIGAT_PARAMS_SIDE_STREAM_ON) ? 1 : 2);
@@ -887,7 +914,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             i > 0 ? ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) | ((p->flags & DIGAT_PQ_FP8) ? 4 : 0) : 0,
                             // after the last layer only the history rows are read (the user context's topic pooling, :124):
                             // the topic nodes' own Eq. 8 is not computed there (wave-per-centre sparse kernel)
-                            (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0, fmt, rflag);
+                            (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0, fmt, rflag,
+                            (i > 0 && lv_on && tw_pub.word) ? &tw_pub : nullptr);
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
@@ -943,8 +971,10 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
 
 // layer 0 of grouped rows (xattn_sparse_l0_kernel): group starts [B + 64] int, rows led by each row [B] bytes, offsets [B + 64] int
 // and list [B U] int of the live centres of the chunk-leading rows
+// + twins (xattn_sparse_twin_kernel): twin words [B U] u32, lead flags [B U] bytes, leads per row [B + 64] int, offsets [B + 64] int, list [B U] int
 static size_t l0_chunk_bytes(int B, int U) {
-    return 2 * align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B, 256) + align_up((size_t)B * U * 4, 256);
+    return 2 * align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B, 256) + align_up((size_t)B * U * 4, 256)
+           + 2 * align_up((size_t)B * U * 4, 256) + align_up((size_t)B * U, 256) + 2 * align_up((size_t)(B + 64) * 4, 256);
 }
 
 size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
