@@ -186,6 +186,9 @@ int digat_xattn_pairwise_fwd(const float* Pr, const float* Q, const float* h, co
 }
 
 struct TwinLists { const unsigned* word; const int* list; const int* count; };     // user_live_flags_kernel's twins (see there)
+// pre-split node rows between two Eq. 8 layers (fp16x3 format): `in` = the rows of X as the previous layer's Eq. 8 kernel stored
+// them for this layer's projection GEMM (GemmArgs.a_split), `out` = where this layer's Eq. 8 kernel stores its output rows for the next
+struct SplitIO { const void* in; unsigned char* out; unsigned* range; };
 
 // Eq. 8 layer with K3 (r = ctx F3^T + b3) already computed; `r_given` may live anywhere
 static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
@@ -194,7 +197,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
                       int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0,
-                      int gemm_format = 0, unsigned* range_flag = nullptr, const TwinLists* tw = nullptr) {
+                      int gemm_format = 0, unsigned* range_flag = nullptr, const TwinLists* tw = nullptr, const SplitIO* sio = nullptr) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -221,6 +224,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
     if (pq8) { g.fp8_segs = 6; g.ldy8 = ld8; if (pq_mode & 2) g.x1_segs = 6; }
     const bool listed = rowidx && gemm_is_bf16x6(g);
     if (listed) { g.rowidx = rowidx; g.nrows_dev = nrows_dev; }                         // live rows only (see user_live_flags_kernel)
+    if (sio && sio->in && listed && gemm_format == 1 && d % 8 == 0) g.a_split = sio->in;    // the rows arrive split: no operand split in the GEMM
     const int rc = launch_gemm(g, st, DIGAT_KERNEL_PROJ);
     if (rc) return rc;
     const int* skip_if = nullptr;
@@ -230,6 +234,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq8 ? 2 : (pq16 ? 1 : 0), plan ? 0 : centre_limit};
         sg.ld8 = pq8 ? ld8 : 0;
         if (tw && listed && live && !plan) { sg.twin = tw->word; sg.twlist = tw->list; sg.twcount = tw->count; }
+        if (sio && sio->out && listed && live && !plan && sparse_mode == DIGAT_XATTN_SPARSE) { sg.xsplit = sio->out; sg.xsplit_range = sio->range; }
         // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
         const int rcs = plan ? launch_staged(sg, *plan, listed && live ? 1 : 0, plan_slot, st) : launch_sparse(sg, st);
         if (rcs || sparse_mode == DIGAT_XATTN_SPARSE) return rcs;
@@ -556,7 +561,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               void* xws, void* xws_news, void* cws, float* kq_t, float* kq_u, float* const r_user2[2],
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
-                              void* chunk_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
+                              void* chunk_ws, unsigned char* xsplit_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
                               const int64_t* news_index, int64_t news_rows, const float* c_n_src) {
     // c_n_src: where the news context stands BEFORE layer 0 — c_n itself, or (depth >= 1, context given) the caller's c_n0, read
     // in place by the two consumers that precede the first update instead of being copied into c_n first
@@ -661,6 +666,14 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     int* const tw_cnt = (int*)(tw_flags + align_up((size_t)B * U, 256));
     int* const tw_off = tw_cnt + align_up((size_t)B + 64, 64);
     TwinLists tw_pub{nullptr, nullptr, nullptr};
+    // Node rows between two layers also as ready-split fp16 pairs (fp16x3 format, sparse Eq. 8 on the live lists): the Eq. 8 kernel of
+    // layer i stores them, the projection GEMM of layer i + 1 reads its A fragments as they are (GemmArgs.a_split; same bits)
+    // MEASURED (round 4): the shipped GEMM loses 5-8 % of its time with it (its step is bound by the lockstep of its two workgroups,
+    // not by the split), the Eq. 8 kernels lose as much storing the second copy: LAB builds only, off by default.
+    static const int presplit_on = LAB_ENV("DIGAT_PRESPLIT", 0);
+    const bool presplit = presplit_on && xsplit_ws && fmt == 1 && want_live && !use_staged && sparse_mode == DIGAT_XATTN_SPARSE &&
+                          d % 8 == 0 && d / 4 <= 256 && U > 16 && (long)B * U >= 2048 && L > 1;
+    bool xs_ready = false;            // the split rows of the CURRENT user nodes exist (written by the previous layer's Eq. 8 kernel)
     auto find_live_rows = [&](hipStream_t sq) -> int {
         int* cnt = live_ws;
         int* off = cnt + align_up((size_t)B, 64);
@@ -880,10 +893,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                 // live centres only (the list of find_live_rows), P / Q / h / X read through the group index.  The staged kernels
                 // (opt-in) keep the older arrangement: every centre computed, and the dead rows of the other buffer filled with X_i
                 const bool l0_live = want_live && live_flags && !use_staged && g_l0_live_on;
-                const SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, l0_live ? live_flags : nullptr,
+                SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, l0_live ? live_flags : nullptr,
                                     sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, xu0_grouped ? 1 : 0,
                                     (!l0_live && xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
                                     l0_live ? rowidx : nullptr, l0_live ? nrows_dev : nullptr, G, nullptr, 0, 0};
+                if (presplit && l0_live && L > 1) { sg.xsplit = xsplit_ws; sg.xsplit_range = rflag; xs_ready = true; }
                 if (l0_chunked && l0_live && sparse_l0_ok(sg)) {
                     // R rows of an impression per wave: every neighbour row fetched serves R rows (xattn_sparse_l0_kernel; same bits)
                     rc = launch_sparse_l0(sg, l0_lead, l0_idx, l0_off + B, G, st);
@@ -908,6 +922,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         } else {
             // every layer projects, scores and writes the live nodes only (layer 0 too: see publish_live_rows above)
             const bool lv_on = i > 0 || (g_l0_live_on && !use_staged);
+            const bool xs_out = presplit && lv_on && rowidx && live_flags && i + 1 < L;
+            const SplitIO sio{xs_ready && lv_on && rowidx ? (const void*)xsplit_ws : nullptr, xs_out ? xsplit_ws : nullptr, rflag};
             rc = xattn_core(Xu[un], Au, r_user, lu.W, lu.bW, lu.F1, lu.F2, lu.a, Xu[un ^ 1], nullptr, B, U, d, xws, st, lu.wsplit,
                             lv_on ? rowidx : nullptr, lv_on ? nrows_dev : nullptr, lv_on ? live_flags : nullptr, sparse_mode,
                             sparse_flag, pq_x3, use_staged ? &plan : nullptr, i,
@@ -915,7 +931,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                             // after the last layer only the history rows are read (the user context's topic pooling, :124):
                             // the topic nodes' own Eq. 8 is not computed there (wave-per-centre sparse kernel)
                             (i > 0 && i == L - 1 && sparse_mode == DIGAT_XATTN_SPARSE) ? H : 0, fmt, rflag,
-                            (i > 0 && lv_on && tw_pub.word) ? &tw_pub : nullptr);
+                            (i > 0 && lv_on && tw_pub.word) ? &tw_pub : nullptr, &sio);
+            xs_ready = sio.out != nullptr;
         }
         if (rc) return rc;
         if (side && hipEventRecord(side->fork, st) != hipSuccess) return DIGAT_ERR_LAUNCH;      // this layer's user nodes are written
@@ -969,6 +986,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     return DIGAT_OK;
 }
 
+#ifdef DIGAT_LAB
+static size_t xsplit_bytes(int B, int U, int d) { return align_up((size_t)B * U * d * 4, 256); }
+#else
+static size_t xsplit_bytes(int, int, int) { return 0; }
+#endif
 // layer 0 of grouped rows (xattn_sparse_l0_kernel): group starts [B + 64] int, rows led by each row [B] bytes, offsets [B + 64] int
 // and list [B U] int of the live centres of the chunk-leading rows
 // + twins (xattn_sparse_twin_kernel): twin words [B U] u32, lead flags [B U] bytes, leads per row [B + 64] int, offsets [B + 64] int, list [B U] int
@@ -992,6 +1014,7 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     // + adjacency entries per row and the sparse / dense decision (int)
     tot += align_up((4 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
                      + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256), 256);
+    tot += xsplit_bytes(B, U, d);                         // LAB builds: the user nodes as split fp16 pairs between two layers (SplitIO)
     tot += l0_chunk_bytes(B, U);                          // layer 0 of grouped rows: group starts + rows led by each row (xattn_sparse_l0_kernel)
     tot += plan_bytes(B, U);                             // the staged Eq. 8 kernel's plan of the batch (digat_staged.inc)
     return tot;
@@ -1044,6 +1067,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     int* live_ws = (int*)((char*)xws_news + digat_xattn_workspace_bytes(B, N, d));
     void* plan_ws = (char*)workspace + digat_encoder_workspace_bytes(B, N, H, C, d, L) - plan_bytes(B, U);
     void* chunk_ws = (char*)plan_ws - l0_chunk_bytes(B, U);
+    unsigned char* xsplit_ws = xsplit_bytes(B, U, d) ? (unsigned char*)chunk_ws - xsplit_bytes(B, U, d) : nullptr;
 
     int rc;
     const bool folded = p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W;
@@ -1077,7 +1101,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     }
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
-                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, Au_g, cm_g, ci_g,
+                                  xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, xsplit_ws, Au_g, cm_g, ci_g,
                                   c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
@@ -1221,6 +1245,9 @@ int digat_user_project0(const digat_params* p, const float* X, float* hpq, int M
     gg.wsplit = (const unsigned short*)lu.wsplit;
     gg.format = (p->flags & DIGAT_PARAMS_GEMM_F16X3) ? 1 : 0; gg.range_flag = gg.format ? (unsigned*)p->range_flag : nullptr;
     gg.m_dispatch = 1 << 30;                                               // the large-M kernel whatever M is (C topic rows)
+#ifdef DIGAT_LAB
+    if (LAB_ENV("DIGAT_LAB_FAKE_PRESPLIT", 0) && gg.format == 1) gg.a_split = X;     // timing only (tools/exp/gemm_lab.py): X read as if already split
+#endif
     return launch_gemm(gg, (hipStream_t)stream, DIGAT_KERNEL_PROJ);
 }
 

@@ -504,6 +504,70 @@ def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     assert torch.equal(live_per_row, every)
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_twin_centres_and_row_chunks_are_bit_identical_to_the_wave_per_centre_kernel(depth):
+    """Round 4: layer 0 serves four rows of an impression per wave (xattn_sparse_l0_kernel) and layers >= 1 serve up to four
+    centres with EQUAL adjacency rows per wave (xattn_sparse_twin_kernel; twins found by user_live_flags_kernel).  Both run only
+    with the live-row lists; with the lists off every centre goes through xattn_sparse_kernel alone — the two must agree bit for
+    bit, and with the oracle.  Users built to stress the twin logic: a whole history in ONE category (50 twins, and the topic
+    node's row equals theirs: a chunk that straddles the last layer's centre limit), two big categories (chunks of 4 + a rest),
+    a one-item history, an empty history; impressions of 1, 2, 5 and 9 candidates (row chunks of every size)."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=1500, sag_neighbors=3, sag_hops=2, impressions=80, mean_candidates=30.0, max_candidates=80, seed=121)
+    corpus = synthetic.make_corpus(spec)
+    H, C = spec.max_history_num, spec.category_num
+    for imp, cats, hl in ((2, np.zeros(H, dtype=np.int64), H), (5, np.full(H, 3, dtype=np.int64), H),
+                          (7, np.r_[np.zeros(H // 2, dtype=np.int64), np.ones(H - H // 2, dtype=np.int64)], H),
+                          (9, np.full(H, 2, dtype=np.int64), 1), (11, np.full(H, 1, dtype=np.int64), 7)):
+        g, cm, ci = synthetic.build_user_graphs(cats[None, :], np.array([hl]), C)
+        corpus.user_graph[imp], corpus.user_category_mask[imp], corpus.user_category_indices[imp] = g[0], cm[0], ci[0]
+        corpus.history[imp] = 0
+        corpus.history[imp, :hl] = np.arange(1, hl + 1)
+    # impressions with 1, 2, 5, 9 candidates: rebuild the row arrays
+    cand = corpus.extra["candidates"].copy()
+    cand[[1, 2, 3, 4]] = [1, 2, 5, 9]
+    rng = np.random.default_rng(5)
+    corpus.row_impression = np.repeat(np.arange(spec.impressions, dtype=np.int64), cand)
+    corpus.row_candidate = rng.integers(1, spec.news_num, size=int(cand.sum())).astype(np.int32)
+    corpus.row_label = np.zeros(int(cand.sum()), dtype=np.int8)
+    state = synthetic.make_state_dict(spec.embedding_dim, C, depth, seed=122, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=H, category_num=C, graph_depth=depth, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    model.graph_encoder.user_xattn_mode = "sparse"
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    with_lists = util.score_rows(model, dc, 0, dc.rows, 1024)
+    with_lists_per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+    with model.graph_encoder.launch_options(live_rows=False):
+        every_centre = util.score_rows(model, dc, 0, dc.rows, 1024)
+    assert torch.isfinite(with_lists).all()
+    assert torch.equal(with_lists, every_centre), float((with_lists - every_centre).abs().max())
+    assert torch.equal(with_lists_per_row, every_centre)
+    # ... and against the oracle on the rows of the crafted users and the odd-sized impressions
+    p = O.as_params(state)
+    emb = torch.from_numpy(corpus.news_embedding)
+    ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
+    sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, spec.embedding_dim)
+    masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+    rows = np.flatnonzero(np.isin(corpus.row_impression, [1, 2, 3, 4, 5, 7, 9, 11]))[:96]
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        imp = torch.from_numpy(corpus.row_impression[rows])
+        candt = torch.from_numpy(corpus.row_candidate[rows].astype(np.int64))
+        hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+        ue = emb.index_select(0, hist.flatten()).view(len(rows), H, spec.embedding_dim)
+        want = O.row_logits(p, depth, ue, torch.from_numpy(corpus.user_graph).index_select(0, imp),
+                            torch.from_numpy(corpus.user_category_mask).index_select(0, imp),
+                            torch.from_numpy(corpus.user_category_indices).index_select(0, imp),
+                            sa.index_select(0, candt), graphs.index_select(0, candt), masks.index_select(0, candt), c_n0.index_select(0, candt))
+    got = with_lists.cpu()[torch.from_numpy(rows)]
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max())), float((got - want).abs().max())
+
+
 @pytest.mark.parametrize("shape", ["default", "large", "stress"])
 def test_staged_eq8_is_bit_identical_to_the_wave_per_centre_kernel(shape):
     """The LDS-staged sparse Eq. 8 kernel (one workgroup per block of centres, rows read once: digat_staged.inc) evaluates

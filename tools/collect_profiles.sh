@@ -28,6 +28,8 @@ python3 tools/pmc_table.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write --match top
 bash tools/exp/solo_trace.sh $OUT/stress --workload mind-small-stress --impressions 4096 > $OUT/stress_solo_kernels.txt 2>&1
 bash tools/exp/solo_trace.sh $OUT/large --workload mind-large-default --impressions 4096 > $OUT/large_solo_kernels.txt 2>&1
 bash tools/exp/solo_trace.sh $OUT/default_solo > $OUT/default_solo_kernels.txt 2>&1
+# the other adjacency regime (full histories in 2-4 categories: 16 entries per node), single-stream kernel table
+bash tools/exp/solo_trace.sh $OUT/heavy --workload mind-small-heavy-history --impressions 4096 > $OUT/heavy_solo_kernels.txt 2>&1
 python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
 # per-kernel averages of the traced run's TIMED REGION only (between bench.py's two marker kernels), next to that run's own line
 python3 tools/trace_region.py $OUT/trace/t_kernel_trace.csv > $OUT/timed_region_kernels.txt 2>&1
