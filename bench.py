@@ -439,6 +439,8 @@ def run_training(W, args, D: Dist, steps, warmup):
     ts.negative_sampling()
     tr = Trainer(W.model, cfg, W.dc, ts, local_rank=(D.device_index if D.world > 1 else -1))
     tr.model.train()
+    if D.world > 1 and hasattr(tr.model, "_set_ddp_runtime_logging_sample_rate"):
+        tr.model._set_ddp_runtime_logging_sample_rate(1)          # DDP's own timers on every iteration (the all-reduce time below)
     nb = len(ts) // 64
     k = 0
 
@@ -465,7 +467,43 @@ def run_training(W, args, D: Dist, steps, warmup):
     for _ in range(steps):
         loss = step()
     D.fence()
-    return types.SimpleNamespace(elapsed=time.perf_counter() - t0, rows_done=steps * 64 * 5, loss=loss)
+    elapsed = time.perf_counter() - t0
+    roof = None
+    if D.world == 1:
+        # untimed: the MFMA launches of three more steps through the library's profiler (forward, input-gradient and
+        # weight-gradient GEMMs: 2 M N K each, six bf16 products per fp32 product unless --train-precision bf16)
+        from digat_amd import _lib
+        _lib.lib().digat_profile_set_kinds(0xffffffff)
+        _lib.profile_start(4096)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        prof = _lib.profile_stop()
+        nprod = 1.0 if args.train_precision == "bf16" else 6.0
+        flops = (prof["proj"]["work"] + prof["linear"]["work"]) / 3.0
+        gemm_ms = (prof["proj"]["ms"] + prof["linear"]["ms"]) / 3.0
+        gemm_bytes = (prof["proj"]["gemm_bytes"] + prof["linear"]["gemm_bytes"]) / 3.0
+
+        def roof(ms_per_step):
+            return {"kernel": "every MFMA launch of the step (forward, input-gradient and weight-gradient GEMMs)", "bound": "mfma",
+                    "achieved": nprod * flops / (ms_per_step * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": nprod * flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_flops_per_step": flops, "executed_flops_per_step": nprod * flops,
+                    "gemm_launch_ms_per_step": gemm_ms, "gemm_hbm_bytes_per_step": gemm_bytes,
+                    "frac_within_the_gemm_launches": nprod * flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gemm_ms > 0 else None,
+                    "note": "a 320-row step is ~250 launches of 5-80 us: the step is bound by launch cadence and by the dense Eq. 8 "
+                            "backward (no sparse / live-row kernels in training yet), not by the matrix cores"}
+    ddp = None
+    if D.world > 1 and hasattr(tr.model, "_get_ddp_logging_data"):
+        try:          # DistributedDataParallel's own measurements (nanoseconds, averaged over the sampled iterations)
+            log = tr.model._get_ddp_logging_data()
+            ddp = {k: round(float(log[k]) / 1e6, 4) for k in ("avg_forward_compute_time", "avg_backward_compute_time", "avg_backward_comm_time",
+                                                                "avg_backward_compute_comm_overlap_time") if k in log}
+            ddp["unit"] = "ms per step (DistributedDataParallel's timers; avg_backward_comm_time = the gradient all-reduce)"
+            ddp["bucket_sizes_bytes"] = str(log.get("bucket_sizes", ""))
+        except Exception as exc:          # the logging API is private: report, never fail the run
+            ddp = {"error": repr(exc)}
+    return types.SimpleNamespace(elapsed=elapsed, rows_done=steps * 64 * 5, loss=loss, roofline=roof, ddp=ddp)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -837,7 +875,10 @@ def main():
                            "news_encoder": ("MSA on title text: %d titles x 32 tokens per rank and step" % (64 * (5 * W.N + W.H))
                                             if args.train_news_encoder == "msa" else "trainable table of news representations"),
                            "parallelism": f"ddp{D.world} (DistributedDataParallel, RCCL all-reduce of the gradients)"},
-                "final_loss": run.loss}))
+                "final_loss": run.loss,
+                # N > 1: the gradient all-reduce as DistributedDataParallel itself times it; N = 1: the step's MFMA launches against the peak
+                "ddp_timers": run.ddp, "backend": D.backend, "ranks_in_process_group": D.world_seen,
+                "roofline": run.roofline(elapsed / args.steps * 1e3) if run.roofline else None}))
         D.close()
         return
 
@@ -1011,11 +1052,13 @@ def main():
         try:
             Wt = build_workload("mind-small-default", args, D, 4096, trainable=True)
             rt = run_training(Wt, args, D, max(4, args.extra_steps), 2)
+            ms_t = rt.elapsed / max(4, args.extra_steps) * 1e3
             extra["mind-small-default/train-step"] = {"value": rt.rows_done / rt.elapsed, "unit": "rows/s",
-                                                      "ms_per_step": rt.elapsed / max(4, args.extra_steps) * 1e3,
+                                                      "ms_per_step": ms_t,
                                                       "rows_per_step": 320, "final_loss": rt.loss,
                                                       "dtype": "f32 (bf16x6 matrix-core products, f32 accumulation)",
-                                                      "what": "64 behaviours x (1 + 4) candidates, graph encoder + trainable news table, dropout 0.2"}
+                                                      "what": "64 behaviours x (1 + 4) candidates, graph encoder + trainable news table, dropout 0.2",
+                                                      "roofline": rt.roofline(ms_t) if rt.roofline else None}
             del Wt, rt
             torch.cuda.empty_cache()
         except Exception as exc:          # the headline must not depend on the training leg

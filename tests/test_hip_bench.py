@@ -75,6 +75,7 @@ def test_bench_single_gpu_prints_the_contract_line():
     rs = line["roofline_step"]
     assert 0 < rs["frac"] < 1 and rs["floor_ms"] == max(rs["mfma_floor_ms"], rs["hbm_floor_ms"]) and rs["bound"] in ("hbm", "mfma")
     assert set(line["untimed_seconds_before_the_timed_region"]) == {"prewarm", "lane_tuning"}
+    assert 0 < ex["mind-small-default/train-step"]["roofline"]["frac"] < 1
     assert ex["mind-small-stress"]["config"]["N"] == 65 and ex["mind-large-default"]["config"]["N"] == 26
     for k in ("mind-small-stress", "mind-large-default", "mind-small-heavy-history"):        # configs[2] / configs[3]: their own rooflines
         assert 0 < ex[k]["roofline"]["frac"] < 1 and 0 < ex[k]["roofline_xattn"]["frac"] < 1 and ex[k]["kernel_ms_per_step_single_stream"]
@@ -128,6 +129,9 @@ def test_bench_train_mode_two_ranks_ddp():
     assert line["n_gpus"] == 2 and line["unit"] == "rows/s" and line["value"] > 0 and "ddp2" in line["config"]["parallelism"]
     import math
     assert math.isfinite(line["final_loss"])
+    # the gradient all-reduce as DistributedDataParallel times it, and the ranks that really rendezvoused
+    assert line["ranks_in_process_group"] == 2 and line["backend"] == "gloo"
+    assert line["ddp_timers"] and ("avg_backward_comm_time" in line["ddp_timers"] or "error" in line["ddp_timers"])
 
 
 def test_bench_train_mode_with_the_msa_news_encoder():
@@ -141,3 +145,4 @@ def test_bench_train_mode_with_the_msa_news_encoder():
     import math
     assert line["unit"] == "rows/s" and line["value"] > 0 and math.isfinite(line["final_loss"])
     assert "MSA" in line["config"]["news_encoder"]
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
