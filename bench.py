@@ -521,7 +521,7 @@ def rooflines(W, run, args):
     dom = max(single, key=single.get) if single else (max(iso_ms, key=iso_ms.get) if iso_ms else max(kinds, key=lambda k: kinds[k]["ms"]))
     symbols = {"proj": "gemm_bf16x6s_kernel<3" if getattr(enc, "projection_mode", "") != "fp32"
                else "gemm_f32_kernel<128, 80, 4, 1, 1, 1>",
-               "xattn": "xattn_sparse" if enc.resolved_xattn_mode("user") == "sparse" else "xattn_score_kernel",
+               "xattn": "xattn_sparse_twin" if enc.resolved_xattn_mode("user") == "sparse" else "xattn_score_kernel",
                "agg": "xattn_agg_kernel", "topic": "topic_pool", "pool": "attn_pool_kernel"}
 
     def pmc_traffic(kind):

@@ -504,6 +504,53 @@ def test_live_row_skipping_does_not_change_outputs(neighbors, hops, L, cats):
     assert torch.equal(live_per_row, every)
 
 
+@pytest.mark.parametrize("mode", ["sparse", "dense", "auto"])
+def test_heavy_history_users_against_the_oracle(mode):
+    """The other adjacency regime (SynthSpec(history_profile="heavy"): 16 entries per node, 79 % of the nodes live, categories of
+    12-25 twins): both Eq. 8 variants and the corpus-driven choice against the oracle on whole impressions, the two variants
+    against each other, live lists on and off bit for bit."""
+    from digat_amd import evaluate, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=40, mean_candidates=30.0, max_candidates=60,
+                               seed=131, history_profile="heavy")
+    corpus = synthetic.make_corpus(spec)
+    L = 3
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=132, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    model.graph_encoder.user_xattn_mode = mode
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    if mode == "auto":
+        assert model.graph_encoder.resolved_xattn_mode("user") == "sparse"          # 16 entries per node: below the threshold of 20
+    got = util.score_rows(model, dc, 0, dc.rows, 1024)
+    with model.graph_encoder.launch_options(live_rows=False):
+        every = util.score_rows(model, dc, 0, dc.rows, 1024)
+    assert torch.equal(got, every)
+    p = O.as_params(state)
+    emb = torch.from_numpy(corpus.news_embedding)
+    ids = torch.from_numpy(corpus.news_node_ID.astype(np.int64))
+    sa = emb.index_select(0, ids.flatten()).view(ids.shape[0], -1, spec.embedding_dim)
+    masks, graphs = torch.from_numpy(corpus.news_graph_mask), torch.from_numpy(corpus.news_graph)
+    n = min(dc.rows, 192)
+    with torch.no_grad():
+        c_n0 = O.news_graph_context(p, sa, masks)
+        imp = torch.from_numpy(corpus.row_impression[:n])
+        cand = torch.from_numpy(corpus.row_candidate[:n].astype(np.int64))
+        hist = torch.from_numpy(corpus.history.astype(np.int64)).index_select(0, imp)
+        ue = emb.index_select(0, hist.flatten()).view(n, spec.max_history_num, spec.embedding_dim)
+        want = torch.cat([O.row_logits(p, L, ue[s:s + 64], torch.from_numpy(corpus.user_graph).index_select(0, imp[s:s + 64]),
+                                       torch.from_numpy(corpus.user_category_mask).index_select(0, imp[s:s + 64]),
+                                       torch.from_numpy(corpus.user_category_indices).index_select(0, imp[s:s + 64]),
+                                       sa.index_select(0, cand[s:s + 64]), graphs.index_select(0, cand[s:s + 64]),
+                                       masks.index_select(0, cand[s:s + 64]), c_n0.index_select(0, cand[s:s + 64])) for s in range(0, n, 64)])
+    g = got.cpu()[:n]
+    assert torch.allclose(g, want, rtol=2e-5, atol=2e-5 * float(want.abs().max())), float((g - want).abs().max())
+
+
 @pytest.mark.parametrize("depth", [2, 3])
 def test_twin_centres_and_row_chunks_are_bit_identical_to_the_wave_per_centre_kernel(depth):
     """Round 4: layer 0 serves four rows of an impression per wave (xattn_sparse_l0_kernel) and layers >= 1 serve up to four
