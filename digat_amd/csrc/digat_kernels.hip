@@ -125,7 +125,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;      // callers pass 0 .. 6; anything else waits for more than asked
     }
 }
 
