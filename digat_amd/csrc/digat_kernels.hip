@@ -513,6 +513,7 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // on a side stream under the user graph's projection / score / aggregation, which fill the chip; fork and join
 // are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
 // caller's stream.
+static size_t l0_chunk_bytes(int B, int U);      // the extra lists of the folded path (defined with the workspace sizes below)
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 // Nothing below is mutable: live-row lists and the side stream are chosen PER CALL through digat_params.flags
 // (DIGAT_PARAMS_NO_LIVE_ROWS, DIGAT_PARAMS_SIDE_STREAM_OFF / _ON), so two host threads with different settings cannot flip each
@@ -956,6 +957,18 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             float* alpha_n = (float*)((char*)xws_news + align_up(3 * ndn * 4, 256) + align_up((size_t)B * d * 4, 256));
             rc = launch_xattn_pairwise(hn + plane, hn + 2 * plane, hn, xn_cur, ln.a, An, Xn[nn], alpha_n, B, N, d, sn, nullptr, nullptr, r_news,
                                        false, nullptr, tab ? news_index : nullptr);
+        } else if (i == 0 && news_hpq0 && news_index) {
+            // Larger news graphs, layer 0 from the per-news TABLES (round 4): [h | P | Q] of a news graph depend on the news alone, so
+            // the projection GEMM of layer 0 (B N rows: at N = 26 the largest launch of a MIND-large step) is replaced by reading the
+            // candidates' rows of the table IN PLACE — the sparse kernel's group indirection with the candidate id as the "group" —
+            // and adding K3 in the kernel, in the GEMM epilogue's order (K3 + K1): the bits of the in-batch launch.
+            const size_t plane = (size_t)news_rows * N * d;
+            int* idx32 = (int*)((char*)chunk_ws + l0_chunk_bytes(B, U) - align_up((size_t)B * 4, 256));
+            hipLaunchKernelGGL(index_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, sn, news_index, idx32, B);
+            DIGAT_CHECK_LAUNCH();
+            SparseArgs sgn{news_hpq0 + plane, news_hpq0 + 2 * plane, news_hpq0, xn_cur, ln.a, An, Xn[nn], r_news, idx32, nullptr,
+                           nullptr, B, N, d / 4, 1, nullptr, nullptr, nullptr, nullptr, (int)news_rows, nullptr, 0, 0};
+            rc = launch_sparse(sgn, sn);
         } else {
             // larger news graphs (N = 26 / 65: the breadth-first SAG, a few entries per node) take the sparse kernel when the
             // caller says so (flags bit 3); there is no device-side decision for this graph
@@ -997,9 +1010,11 @@ static size_t xsplit_bytes(int, int, int) { return 0; }
 // layer 0 of grouped rows (xattn_sparse_l0_kernel): group starts [B + 64] int, rows led by each row [B] bytes, offsets [B + 64] int
 // and list [B U] int of the live centres of the chunk-leading rows
 // + twins (xattn_sparse_twin_kernel): twin words [B U] u32, lead flags [B U] bytes, leads per row [B + 64] int, offsets [B + 64] int, list [B U] int
+// + [B] int: the candidate ids as 32-bit indices (layer 0 of larger news graphs from the per-news tables)
 static size_t l0_chunk_bytes(int B, int U) {
     return 2 * align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B, 256) + align_up((size_t)B * U * 4, 256)
-           + 2 * align_up((size_t)B * U * 4, 256) + align_up((size_t)B * U, 256) + 2 * align_up((size_t)(B + 64) * 4, 256);
+           + 2 * align_up((size_t)B * U * 4, 256) + align_up((size_t)B * U, 256) + 2 * align_up((size_t)(B + 64) * 4, 256)
+           + align_up((size_t)B * 4, 256);
 }
 
 size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
@@ -1043,7 +1058,9 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     if (B == 0) return DIGAT_OK;
     // per-news tables read in place: only where layer 0 of the news graph is the one reader of the node table (given c_n0,
     // cached projections, the small-graph kernel)
-    if (news_index && !(c_n0 && news_hpq0 && L > 0 && N <= 16 && d / 4 <= 256 && news_rows > 0 &&
+    // ... or, for larger news graphs (round 4), the sparse Eq. 8 kernel through the candidate ids (flags: DIGAT_NEWS_XATTN_SPARSE)
+    if (news_index && !(c_n0 && news_hpq0 && L > 0 && d / 4 <= 256 && news_rows > 0 && news_rows <= 0x7fffffffLL &&
+                        (N <= 16 || ((p->flags & DIGAT_NEWS_XATTN_SPARSE) && N <= DIGAT_MAX_NODES)) &&
                         p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W)) return DIGAT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
 

@@ -23,6 +23,7 @@ import torch
 from . import evaluate
 
 
+NEWS_TABLE_MAX_BYTES = 48 << 30     # layer-0 [h|P|Q] tables of news graphs of more than 16 nodes are kept up to this size (288 GB of HBM per GPU)
 SPARSE_ENTRIES_PER_NODE = 20        # the library's own threshold for DIGAT_XATTN_AUTO (digat_kernels.hip); measured at 15.7 entries per node
                                     # (heavy histories, bench.py): sparse 5.34 vs dense 6.11 ms per 4096-row step; break-even extrapolates to ~21
 
@@ -132,8 +133,14 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
     dc.c_n0 = c_n0
     # ... and, in the same spirit, layer 0's projections of the news graph, which depend on the news alone (small news graphs:
     # the kernel that consumes them adds K3 itself).  [3, news_num, N, d] fp32: 3.1 GB for MIND-small at N = 10.
+    # Larger news graphs (N = 26, 65) keep the table too when their Eq. 8 runs on the sparse kernel, which reads the candidates' rows
+    # in place (round 4: the layer-0 projection GEMM of B N rows was the largest launch of a MIND-large step); 20 GB at MIND-large
+    # scale and at MIND-small stress scale, of 288 — bounded by NEWS_TABLE_MAX_BYTES.
     dc.news_hpq0 = None
-    if N <= 16 and d % 4 == 0 and d <= 1024 and hasattr(encoder, "project_news_layer0") and getattr(encoder, "graph_depth", 0) > 0:
+    table_bytes = 3 * news_num * N * d * 4
+    big_ok = (N > 16 and table_bytes <= NEWS_TABLE_MAX_BYTES and hasattr(encoder, "resolved_xattn_mode")
+              and encoder.resolved_xattn_mode("news") == "sparse" and news_num < 2 ** 31)
+    if (N <= 16 or big_ok) and d % 4 == 0 and d <= 1024 and hasattr(encoder, "project_news_layer0") and getattr(encoder, "graph_depth", 0) > 0:
         table = torch.empty((3, news_num, N, d), dtype=torch.float32, device=dc.news_embedding.device)
         chunk = max(batch_size, 4096)
         with torch.no_grad():
@@ -162,7 +169,9 @@ def weights_key(encoder, dc: DeviceCorpus) -> tuple:
     pm = encoder.resolved_projection_mode() if hasattr(encoder, "resolved_projection_mode") else getattr(encoder, "projection_mode", None)
     fmt = encoder.gemm_format() if hasattr(encoder, "gemm_format") else None
     # ... and the kernel that computes the context-query table (the encoder's pass_rows names it: same bits as inside a pass)
-    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt, getattr(encoder, "pass_rows", 0) >= 2048)
+    # ... and whether the news graph's Eq. 8 reads the layer-0 table in place (larger news graphs: only the sparse kernel can)
+    news_mode = getattr(encoder, "news_xattn_mode", None)
+    return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt, getattr(encoder, "pass_rows", 0) >= 2048, news_mode)
 
 
 def gather_batch(dc: DeviceCorpus, start: int, end: int):
@@ -221,7 +230,8 @@ class GroupedBatchPipeline:
 
         import os
         in_place_tables = in_place_tables and os.environ.get("DIGAT_IN_PLACE", "1") != "0"          # A/B switch for measurements
-        in_place = dc.news_hpq0 is not None and N <= 16 and d % 4 == 0 and d <= 1024 and in_place_tables
+        in_place = dc.news_hpq0 is not None and d % 4 == 0 and d <= 1024 and in_place_tables
+        gathered_tables = dc.news_hpq0 is not None and not in_place and N <= 16        # larger news graphs: in place or not at all
 
         def bufs():
             return dict(hist=torch.empty((Gmax, H), dtype=torch.int64, device=dev),
@@ -233,12 +243,12 @@ class GroupedBatchPipeline:
                         news_graph=torch.empty((B, N, N), dtype=dc.news_graph.dtype, device=dev),
                         news_mask=torch.empty((B, N), dtype=dc.news_graph_mask.dtype, device=dev),
                         c_n0=torch.empty((B, d), dtype=torch.float32, device=dev),
-                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if dc.news_hpq0 is not None and not in_place else None),
+                        hpq=(torch.empty((3 * B * N * d,), dtype=torch.float32, device=dev) if gathered_tables else None),
                         hist_hpq=(torch.empty((3 * Gmax * H * d,), dtype=torch.float32, device=dev) if dc.user_hpq0 is not None else None),
                         ctxq=(torch.empty((3 * B * d,), dtype=torch.float32, device=dev) if dc.ctxq0 is not None else None))
         # the news side's layer-0 tables (and the node table behind them) are read IN PLACE through the candidate ids when the
         # encoder can (small news graphs: digat_encoder_fwd_grouped_cached's news_index): no gathered copies of 65 MB per batch
-        self.in_place = dc.news_hpq0 is not None and N <= 16 and d % 4 == 0 and d <= 1024 and in_place_tables
+        self.in_place = in_place
         self.sets = [bufs() for _ in range(nsets)]
         uniq_parts, rg_parts, self.uo, self.ro = [], [], [0], [0]
         for s, e in self.batches:

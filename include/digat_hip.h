@@ -289,7 +289,11 @@ int digat_encoder_fwd_grouped(const digat_params* params,
  * the news representations and c_n0 the reference's driver caches per news (util.py:24-44).  digat_news_project0 computes
  * them for M news graphs: Xn [M,N,d] -> hpq [3][M,N,d] (the launch the encoder itself makes; M*N >= 2048 rows for the bf16x6
  * kernel).  digat_encoder_fwd_grouped_cached takes the batch's rows of that table (news_hpq0 [3][B,N,d], gathered by the
- * caller; NULL = compute as usual) and skips the projection GEMM of layer 0 when N <= 16.  Results are bit-identical. */
+ * caller; NULL = compute as usual) and skips the projection GEMM of layer 0 when N <= 16.  Results are bit-identical.
+ * With news_index (the candidate ids; news_graph_embeddings and news_hpq0 are then the whole per-news tables, news_rows rows) the
+ * rows are read IN PLACE: by the graph-in-LDS kernel for N <= 16, and — round 4 — by the sparse Eq. 8 kernel for larger news graphs
+ * when digat_params.flags has DIGAT_NEWS_XATTN_SPARSE (N = 26, 65: the layer-0 projection GEMM of B N rows, the largest launch of a
+ * MIND-large step, goes away; K3 joins in the kernel in the GEMM epilogue's order: the bits of the in-batch launch). */
 int digat_news_project0(const digat_params* params, const float* Xn, float* hpq, int M, int N, void* stream);
 /* The USER graph's layer-0 projections are row-wise too: those of a history node depend on that news alone, those of a topic
  * node on nothing.  digat_user_project0: X [M,d] -> hpq [3][M,d] with user[0]'s [W|ffn1|ffn2] (for the news table, M = number

@@ -944,6 +944,40 @@ def test_cached_news_projections_reproduce_the_in_batch_bits():
     assert torch.equal(with_tables, without) and torch.equal(news_only, without) and torch.equal(with_tables, per_row)
 
 
+@pytest.mark.parametrize("neighbors,cats,L", [(5, 18, 3), (8, 17, 2)], ids=["large-N26", "stress-N65"])
+def test_larger_news_graphs_read_their_layer0_table_in_place(neighbors, cats, L):
+    """Round 4: news graphs of more than 16 nodes (N = 26, 65) on the sparse Eq. 8 kernel take layer 0's [h|P|Q] from the per-news
+    table too — the candidates' rows read in place through their ids, K3 added in the kernel in the GEMM epilogue's order — instead
+    of projecting B N rows per batch: same bits as the in-batch projection (tables off), grouped and per row, ragged last batch."""
+    from digat_amd import synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    spec = synthetic.SynthSpec(news_num=700, sag_neighbors=neighbors, sag_hops=2, category_num=cats, impressions=110, mean_candidates=30.0,
+                               max_candidates=80, seed=97)
+    corpus = synthetic.make_corpus(spec)
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=98, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 1024)
+    N = spec.news_graph_size
+    assert N > 16 and model.graph_encoder.resolved_xattn_mode("news") == "sparse"
+    assert dc.news_hpq0 is not None and tuple(dc.news_hpq0.shape) == (3, 700, N, spec.embedding_dim)
+    with_table = util.score_rows(model, dc, 0, dc.rows, 1024)
+    in_batch = util.score_rows(model, dc, 0, dc.rows, 1024, in_place_tables=False)        # larger graphs: in place or not at all
+    per_row = util.score_rows(model, dc, 0, dc.rows, 1024, grouped=False)
+    assert torch.isfinite(with_table).all()
+    assert torch.equal(with_table, in_batch), float((with_table - in_batch).abs().max())
+    assert torch.equal(with_table, per_row)
+    # a dense news graph cannot read the table in place: no table is kept then
+    model.graph_encoder.news_xattn_mode = "dense"
+    dense = util.score_rows(model, dc, 0, dc.rows, 1024)
+    assert dc.news_hpq0 is None and torch.isfinite(dense).all()
+    assert torch.allclose(dense, with_table, rtol=2e-5, atol=2e-5 * float(with_table.abs().max()))
+
+
 @pytest.mark.parametrize("mode", ["auto", "dense", "sparse"])
 def test_layer0_tables_with_every_eq8_variant(mode):
     """The per-news layer-0 tables feed whichever Eq. 8 variant runs (the dense pair expands the groups' P, the sparse kernel
