@@ -1048,19 +1048,24 @@ def main():
                     extra[other]["auc_match"] = am2
             del W2, r2
             torch.cuda.empty_cache()
-        # the DDP training step of the same shapes (trainer.py:71-105; `--mode train` times it alone): forward, backward, clip, Adam
+        # the DDP training step of the same shapes (trainer.py:71-105): forward, backward, clip, Adam — `bench.py --mode train` as a CHILD
+        # process (the step is ~560 small launches and sits close to being host-bound: inside this process, after the workloads above,
+        # it measured anywhere between 7.3 and 16 ms on the same kernels; a fresh process is what a training run is)
         try:
-            Wt = build_workload("mind-small-default", args, D, 4096, trainable=True)
-            rt = run_training(Wt, args, D, max(4, args.extra_steps), 2)
-            ms_t = rt.elapsed / max(4, args.extra_steps) * 1e3
-            extra["mind-small-default/train-step"] = {"value": rt.rows_done / rt.elapsed, "unit": "rows/s",
-                                                      "ms_per_step": ms_t,
-                                                      "rows_per_step": 320, "final_loss": rt.loss,
+            import subprocess
+            nt = max(4, args.extra_steps)
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", str(nt), "--warmup", "2", "--impressions", "4096",
+                   "--train-precision", args.train_precision]
+            if args.news:
+                cmd += ["--news", str(args.news)]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            tl = json.loads([l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1])
+            extra["mind-small-default/train-step"] = {"value": tl["value"], "unit": "rows/s", "ms_per_step": tl["ms_per_step"],
+                                                      "rows_per_step": 320, "steps": nt, "final_loss": tl["final_loss"],
                                                       "dtype": "f32 (bf16x6 matrix-core products, f32 accumulation)",
-                                                      "what": "64 behaviours x (1 + 4) candidates, graph encoder + trainable news table, dropout 0.2",
-                                                      "roofline": rt.roofline(ms_t) if rt.roofline else None}
-            del Wt, rt
-            torch.cuda.empty_cache()
+                                                      "what": "64 behaviours x (1 + 4) candidates, graph encoder + trainable news table, dropout 0.2; "
+                                                              "timed in a child process (`bench.py --mode train`)",
+                                                      "roofline": tl.get("roofline")}
         except Exception as exc:          # the headline must not depend on the training leg
             extra["mind-small-default/train-step"] = {"error": repr(exc)}
 

@@ -967,7 +967,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             hipLaunchKernelGGL(index_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, sn, news_index, idx32, B);
             DIGAT_CHECK_LAUNCH();
             SparseArgs sgn{news_hpq0 + plane, news_hpq0 + 2 * plane, news_hpq0, xn_cur, ln.a, An, Xn[nn], r_news, idx32, nullptr,
-                           nullptr, B, N, d / 4, 1, nullptr, nullptr, nullptr, nullptr, (int)news_rows, nullptr, 0, 0};
+                           nullptr, B, N, d / 4, 1, nullptr, nullptr, nullptr, nullptr, B, nullptr, 0, 0};      // G (profiling: distinct rows behind the index): at most B candidates
             rc = launch_sparse(sgn, sn);
         } else {
             // larger news graphs (N = 26 / 65: the breadth-first SAG, a few entries per node) take the sparse kernel when the
