@@ -101,6 +101,7 @@ def parse_args():
     ap.add_argument("--train-news-encoder", default="table", choices=["table", "msa"],
                     help="--mode train: 'table' = news representations from a trainable table (graph-encoder step only); 'msa' = the "
                          "reference's full step, MSA news encoder on the titles of 64 x (5 x N + H) news per step")
+    ap.add_argument("--detail", default=None, help="where the full result document goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--projection", default="auto", choices=["auto", "bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1", "pq-fp8", "fp16x3"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
                          "configs[4]: P', Q of the user graph's Eq. 8 stored in bf16 (three bf16 products; -x1: one); pq-fp8: stored as block-scaled e4m3")
@@ -144,10 +145,19 @@ class Dist:
         torch.cuda.set_device(self.device_index)
         self.dev = torch.device("cuda", self.device_index)
         self.ctl_dev = torch.device("cpu") if self.shared_gpu else self.dev
+        self.nccl_log = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             self.backend = "gloo" if self.shared_gpu else "nccl"                   # nccl = RCCL on ROCm
+            if self.backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+                # first-run insurance for the 8-GPU node: RCCL's own account of the transports it chose (xGMI P2P / SHM / NET),
+                # per rank, to a file; rank 0 condenses its file into the line (rccl_summary)
+                import tempfile
+                self.nccl_log = os.path.join(tempfile.gettempdir(), f"digat_bench_rccl_{os.environ.get('MASTER_PORT', '0')}_r{self.rank}.log")
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH"
+                os.environ["NCCL_DEBUG_FILE"] = self.nccl_log
             dist.init_process_group(self.backend)
             self.world_seen = dist.get_world_size()
         else:
@@ -172,6 +182,26 @@ class Dist:
         if self.world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
+
+    def rccl_summary(self):
+        """Rank 0's RCCL log condensed: which transports the channels use and how many rings / trees were built."""
+        if self.world == 1:
+            return None
+        if not self.nccl_log:
+            return {"backend": self.backend, "log": None}
+        import re
+        try:
+            text = open(self.nccl_log, errors="replace").read()
+        except OSError as exc:
+            return {"backend": self.backend, "log": self.nccl_log, "error": repr(exc)}
+        via = {}
+        for m in re.finditer(r"\bvia\s+([A-Za-z0-9_/]+)", text):
+            via[m.group(1)] = via.get(m.group(1), 0) + 1
+        nranks = re.findall(r"nranks\s+(\d+)", text)
+        return {"backend": self.backend, "log": self.nccl_log, "log_bytes": len(text), "channel_transports": via,
+                "mentions_xgmi": len(re.findall(r"(?i)xgmi", text)), "nranks_in_log": sorted(set(int(v) for v in nranks)),
+                "rings_or_trees": len(re.findall(r"(?m)\b(Ring|Tree|Trees)\b", text)),
+                "version_line": next((l.strip()[-120:] for l in text.splitlines() if "version" in l.lower()), None)}
 
     def device_names(self):
         """Every rank's device as it names itself (rank order): evidence of WHICH GPUs a multi-GPU line ran on."""
@@ -266,6 +296,7 @@ class Scorer:
         self.k, self.base, self.pipe, self.order = 0, 0, None, None
         self.kept = [] if keep_scores else None
         enc = W.model.graph_encoder
+        util.apply_corpus_hint(enc, W.dc)            # this corpus's sparse / dense choice (several workloads share the process)
         if hasattr(enc, "pass_rows"):
             # rows per pass name the kernel of the [B,d] linears (util.score_rows does the same); per-news tables made under the
             # other name are rebuilt, untimed
@@ -288,7 +319,10 @@ class Scorer:
                 self.join()
                 with torch.cuda.stream(self.lanes[0]):
                     self.pipe.drain()
-            self.pipe = None if self.per_row else util.GroupedBatchPipeline(W.dc, self.order, self.imp_host, nsets=len(self.lanes))
+            enc = W.model.graph_encoder
+            self.pipe = None if self.per_row else util.GroupedBatchPipeline(
+                W.dc, self.order, self.imp_host, nsets=len(self.lanes),
+                news_sparse=(enc.resolved_xattn_mode("news") == "sparse") if hasattr(enc, "resolved_xattn_mode") else None)
             for extra in self.lanes[1:]:
                 extra.wait_stream(self.lanes[0])
         s, e = self.order[k - self.base]
@@ -599,9 +633,36 @@ def rooflines(W, run, args):
     rx = None
     if "xattn" in kinds:
         rx = roof("xattn")
-        rx["bytes_note"] = ("bytes that must cross HBM once: live centres x (5 d 4 + n) on row-list launches (device count), "
-                            "distinct group rows at layer 0, the news graph's fused launch at SURVEY 8d's bytes_B; "
-                            "launches = user-graph and news-graph Eq. 8 kernels together")
+        rx["bytes_note"] = ("bytes that must cross HBM once (each distinct row once): layers >= 1 of the user graph: live centres x "
+                            "(5 d 4 + n), counted on the device; layer 0 of grouped rows: live nodes of a GROUP x (4 d 4 + n) + live "
+                            "(row, centre) x d 4 (output) + K3 per row; the news graph's fused launch at SURVEY 8d's bytes_B; "
+                            "launches = user-graph and news-graph Eq. 8 kernels together, `parts` = per kernel")
+        # the three Eq. 8 kernels apart (digat_profile_xattn_parts): algorithmic bytes, launch time in the timed region and alone,
+        # and the counter bytes of the same kernel from the newest profiles/*_pmc.json
+        part_symbol = {"twin": "xattn_sparse_twin", "l0": "xattn_sparse_l0", "news": "xattn_small_lds"}
+        parts = {}
+        for name, v in kinds["xattn"].get("parts", {}).items():
+            if v["launches"] <= 0 or v["ms"] <= 0:
+                continue
+            e = {"algorithmic_bytes_per_launch": v["work"] / v["launches"], "launches": v["launches"],
+                 "avg_launch_us": 1e3 * v["ms"] / v["launches"], "achieved": v["work"] / (v["ms"] * 1e-3) / 1e9,
+                 "frac": v["work"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            vi = (prof_iso.get("xattn") or {}).get("parts", {}).get(name)
+            if vi and vi["launches"] > 0 and vi["ms"] > 0:
+                e["isolated_avg_launch_us"] = 1e3 * vi["ms"] / vi["launches"]
+                e["isolated_achieved"] = vi["work"] / (vi["ms"] * 1e-3) / 1e9
+                e["isolated_frac"] = e["isolated_achieved"] / HBM_PEAK_GBS
+                e["isolated_algorithmic_bytes_per_launch"] = vi["work"] / vi["launches"]
+            if name in part_symbol:
+                symbols["xattn/" + name] = part_symbol[name]
+                t = pmc_traffic("xattn/" + name)
+                if t:
+                    e["traffic"] = t["bytes_per_launch"]
+                    e["traffic_source"] = t["source"]
+                    e["kernel"] = t["kernel"]
+            parts[name] = e
+        rx["parts"] = parts
+        rx["unit_note"] = "achieved / isolated_achieved in GB/s against the 8 TB/s HBM peak; bytes per launch"
     # per-kind time per step with the batches overlapped as in the timed region: from the untimed all-kinds pass (the timed
     # region records proj and xattn only)
     if getattr(run, "prof_all", None):
@@ -853,6 +914,117 @@ def workload_config(W, args, D):
             "backend": D.backend, "ranks_in_process_group": D.world_seen}
 
 
+def _r(v, nd=4):
+    """Rounded copy for the compact line (numbers only)."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}") if abs(v) < 1 else round(v, nd)
+    return v
+
+
+def compact_line(out):
+    """The driver's line: the contract fields, the rooflines, the CPU baseline and the parity checks of the full document in <= 4 KB
+    (the full document goes to bench_detail.json: round 4's 26 KB single line did not survive the driver's 8 KB stdout tail)."""
+    def pick(dct, keys):
+        return None if dct is None else {k: _r(dct[k]) for k in keys if k in dct and dct[k] is not None}
+    cfg = out.get("config") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "valid")}
+    c["value"], c["ms_per_step"] = _r(c["value"], 2), _r(c["ms_per_step"], 4)
+    c["config"] = {k: cfg[k] for k in ("workload", "projection", "rows_per_step", "N", "U", "d", "graph_depth", "news_num", "parallelism",
+                                       "backend", "ranks_in_process_group") if k in cfg}
+    roof = out.get("roofline")
+    if roof:
+        r = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "isolated_frac", "isolated_achieved", "avg_launch_ms",
+                        "isolated_avg_launch_ms", "launches"))
+        t = roof.get("traffic")
+        r["traffic"] = None if not t else _r(float(t["bytes_per_launch"]), 0)
+        if t:
+            r["traffic_unit"] = "HBM bytes per launch, 2*FETCH_SIZE+WRITE_SIZE (%s)" % t.get("source", "profiles/")
+        for k in ("algorithmic_flops_per_launch", "executed_flops_per_launch"):
+            if k in roof:
+                r[k] = _r(float(roof[k]), 0)
+        c["roofline"] = r
+    rx = out.get("roofline_xattn")
+    if rx:
+        x = pick(rx, ("bound", "achieved", "peak", "unit", "frac", "isolated_frac", "isolated_achieved"))
+        x["parts"] = {}
+        for name, e in (rx.get("parts") or {}).items():
+            x["parts"][name] = {"us": _r(e["avg_launch_us"], 1), "frac": _r(e["frac"], 3),
+                                "solo_us": _r(e.get("isolated_avg_launch_us"), 1) if e.get("isolated_avg_launch_us") else None,
+                                "solo_frac": _r(e.get("isolated_frac"), 3) if e.get("isolated_frac") else None,
+                                "alg_MB": _r(e.get("isolated_algorithmic_bytes_per_launch", e["algorithmic_bytes_per_launch"]) / 1e6, 1),
+                                "pmc_MB": _r(e["traffic"] / 1e6, 1) if e.get("traffic") else None}
+        c["roofline_xattn"] = x
+    rs = out.get("roofline_step")
+    if rs:
+        c["roofline_step"] = pick(rs, ("frac", "floor_ms", "bound", "mfma_floor_ms", "hbm_floor_ms"))
+    cb = out.get("cpu_baseline")
+    c["cpu_baseline"] = None if cb is None else {**pick(cb, ("value", "unit", "cores", "kind")), "sample": cb["sample"][:150]}
+    am, at = out.get("auc_match"), out.get("auc_match_trained")
+    c["auc_match"] = pick(am, ("max_abs_metric_diff", "tolerance", "rows", "max_abs_score_diff"))
+    c["auc_match_trained"] = pick(at, ("max_abs_metric_diff", "tolerance", "rows", "ranks_equal_fraction"))
+    c["fp16x3_range_overflow"] = out.get("fp16x3_range_overflow")
+    for k in ("per_rank_impressions_per_s", "scaling_efficiency", "all_gather_ms_by_rank", "devices", "rccl"):
+        if out.get(k) is not None and out["n_gpus"] > 1:
+            c[k] = out[k]
+    if out.get("n1_same_workload"):
+        c["n1_same_workload"] = pick(out["n1_same_workload"], ("value", "unit", "ms_per_step"))
+    if out.get("configs4_inference"):
+        c["configs4_inference"] = out["configs4_inference"]
+    ex = out.get("extra_workloads")
+    if ex:
+        # one number per extra workload (impressions/s unless the key says otherwise) + its own oracle check where it has one
+        cx = {}
+        for k, v in ex.items():
+            if "error" in v:
+                cx[k] = "error"
+                continue
+            e = {"value": _r(v["value"], 1), "ms": _r(v.get("ms_per_step"), 3)}
+            if v.get("unit") != "impressions/s":
+                e["unit"] = v.get("unit")
+            if v.get("auc_match"):
+                e["auc_diff"] = _r(v["auc_match"]["max_abs_metric_diff"])
+            if v.get("max_abs_metric_diff_vs_reference_trained_2k") is not None:
+                e["drift_trained"] = _r(v["max_abs_metric_diff_vs_reference_trained_2k"])
+            if "one_stream" in v:
+                e["three_streams"] = _r(v["three_streams"]["value"], 1)
+            for rk in ("roofline", "roofline_xattn", "roofline_step"):
+                if isinstance(v.get(rk), dict) and v[rk].get("frac") is not None:
+                    e[rk[9:] or "roof"] = _r(v[rk]["frac"], 3)
+            cx[k] = e
+        c["extra_workloads"] = cx
+    if out.get("e2e"):
+        c["e2e_seconds"] = out["e2e"]["seconds"]
+    c["detail"] = out.get("detail_file")
+    return c
+
+
+def emit(out, args):
+    """Write the full document to bench_detail.json (next to bench.py, and under gpurun_out/ when that directory exists) and print
+    the compact line as the ONLY line on stdout."""
+    paths = [os.path.join(REPO, "bench_detail.json")]
+    if os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        paths.append(os.path.join(REPO, "gpurun_out", "bench_detail.json"))
+    if getattr(args, "detail", None):
+        paths = [args.detail]
+    written = None
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            written = written or path
+        except OSError as exc:
+            print(f"[bench] could not write {path}: {exc}", file=sys.stderr)
+    out["detail_file"] = os.path.relpath(written, REPO) if written else None
+    line = json.dumps(compact_line(out), separators=(",", ":"))
+    if len(line) > 6000:          # the driver reads the tail of stdout: never let the line outgrow it again
+        c = compact_line(out)
+        c.pop("extra_workloads", None)
+        line = json.dumps(c, separators=(",", ":"))
+    print(line, flush=True)
+
+
 def main():
     args = parse_args()
     D = Dist(args)
@@ -1030,6 +1202,12 @@ def main():
                             "kernel_ms_per_step": kms2,
                             "kernel_ms_per_step_single_stream": kiso2, "live_row_fraction": r2.live_fraction,
                             "config": workload_config(W2, args, D)}
+            if other != "mind-small-heavy-history" and args.cpu_rows > 0:
+                # configs[2] / configs[3]: news graphs of 65 / 26 nodes take layer 0 from the per-news table through the sparse kernel's
+                # group indirection — hold this workload's scores to the fp32 oracle too (a few whole impressions, <= 384 rows)
+                _, am2, _ = cpu_baseline_and_auc(W2, args, min(args.cpu_rows, 384), min(args.cpu_seconds, 12.0), report_baseline=False)
+                extra[other]["auc_match"] = am2
+                extra[other]["news_layer0_table_in_place"] = W2.dc.news_hpq0 is not None
             if other == "mind-small-heavy-history":
                 # the adjacency regime decides the Eq. 8 variant: say which one ran, time the other one too, and hold the scores of a
                 # ~1 500-row sample to the fp32 oracle (the same criterion as the headline's auc_match)
@@ -1082,6 +1260,16 @@ def main():
         setup_s = e2e["breakdown_s"]["news_encoder_msa_65k_titles"] + e2e["breakdown_s"]["prepare_news_side"]
         e2e["steady_state_rate_with_setup_folded_in_impressions_per_s"] = MIND_SMALL_DEV_IMPRESSIONS / (nb * step_s + setup_s)
 
+    # BASELINE configs[4], inference half, decided from the two extras above: the reduced-precision setting that stays within the
+    # reference's 1e-4 on the trained, reference-pinned dev set, and what the fp8 storage costs
+    configs4 = None
+    if extra and "mind-small-default/pq-bf16" in extra and "mind-small-default/pq-fp8" in extra:
+        b16, f8 = extra["mind-small-default/pq-bf16"], extra["mind-small-default/pq-fp8"]
+        def verdict(v):
+            dr = v["max_abs_metric_diff_vs_reference_trained_2k"]
+            return "not measured" if dr is None else ("%.1e (%s 1e-4)" % (dr, "within" if dr <= 1e-4 else "OVER"))
+        configs4 = ("pq-bf16: drift %s, %.0f imp/s; pq-fp8 (block-scaled e4m3 storage of P', Q; no fp8 MFMA: the operands feed a relu, not "
+                    "a product): drift %s, %.0f imp/s, opt-in" % (verdict(b16), b16["value"], verdict(f8), f8["value"]))
     nb_corpus = max(1, W.corpus.rows // args.batch)
     out = {
         "metric": "MIND dev impressions scored/sec (AUC-matched)" if matched else
@@ -1134,11 +1322,13 @@ def main():
         # the same criterion on a model that RANKS (trained weights, planted-signal corpus), against the imported reference's scores
         "auc_match_trained": trained,
         "fp16x3_range_overflow": range_overflow,
+        "configs4_inference": configs4,
+        "rccl": D.rccl_summary(),
         "extra_workloads": extra,
         # the whole dev run of util.compute_scores at MIND-small dev scale, from title tokens to the rank file (seconds)
         "e2e": e2e,
     }
-    print(json.dumps(out))
+    emit(out, args)
     D.close()
     if (auc_match is not None or trained is not None) and not matched:
         raise SystemExit(3)

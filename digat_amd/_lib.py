@@ -160,9 +160,11 @@ _SIGNATURES = {
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
     "digat_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "digat_profile_marker": (C.c_int, [C.c_int, _f]),
+    "digat_profile_xattn_parts": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
+XATTN_PARTS = ("twin", "l0", "news", "other")      # digat_profile_xattn_parts: the Eq. 8 launches by kernel
 EXPORTED = tuple(_SIGNATURES)
 
 
@@ -236,7 +238,12 @@ def profile_stop():
     check(lib().digat_profile_stop(ms, work, cnt), "digat_profile_stop")
     gb = (C.c_double * n)()
     check(lib().digat_profile_gemm_bytes(gb), "digat_profile_gemm_bytes")
-    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i], "gemm_bytes": gb[i]} for i, k in enumerate(KERNEL_KINDS)}
+    out = {k: {"ms": ms[i], "work": work[i], "launches": cnt[i], "gemm_bytes": gb[i]} for i, k in enumerate(KERNEL_KINDS)}
+    m = len(XATTN_PARTS)
+    pms, pby, pcnt = (C.c_double * m)(), (C.c_double * m)(), (C.c_int * m)()
+    check(lib().digat_profile_xattn_parts(pms, pby, pcnt), "digat_profile_xattn_parts")
+    out["xattn"]["parts"] = {k: {"ms": pms[i], "work": pby[i], "launches": pcnt[i]} for i, k in enumerate(XATTN_PARTS)}
+    return out
 
 
 def split_buffer(nbytes: int, device: torch.device) -> torch.Tensor:

@@ -60,14 +60,23 @@ static struct {
     unsigned kind_mask;                // only launches of these kinds are bracketed (digat_profile_set_kinds)
     double* bytes;                     // MFMA kinds: the operand + result bytes of the launch (digat_profile_gemm_bytes)
     double bytes_per_row[16];
-} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}, ~0u, nullptr, {0.0}};
+    int* part;                         // DIGAT_KERNEL_XATTN launches: which Eq. 8 kernel (XPART_*; digat_profile_xattn_parts)
+} g_prof = {0, 0, 0, nullptr, nullptr, nullptr, nullptr, {0.0}, {0.0}, ~0u, nullptr, {0.0}, nullptr};
+
+// The Eq. 8 launches are three unlike kernels with their own byte budgets: they are timed and priced apart (bench.py:
+// roofline_xattn.parts).  Device-side byte counts of a part (live-row lists: known on the device only) go to rows_dev[8 + part].
+enum { XPART_TWIN = 0,      // user graph, layers >= 1: row-list launches (twin kernel / wave per live centre)
+       XPART_L0 = 1,        // user graph, layer 0 of grouped rows (chunk kernel / wave per live centre through the group index)
+       XPART_NEWS = 2,      // news graphs of <= 16 nodes, the graph in LDS (fused)
+       XPART_OTHER = 3,     // everything else: dense score launches, larger news graphs on the sparse kernel
+       XATTN_PARTS = 4 };
 
 struct ProfScope {
     hipStream_t st; int slot;
-    ProfScope(int kind, double work, hipStream_t s, double bytes = 0.0) : st(s), slot(-1) {
+    ProfScope(int kind, double work, hipStream_t s, double bytes = 0.0, int part = XPART_OTHER) : st(s), slot(-1) {
         if (g_prof.enabled && ((g_prof.kind_mask >> kind) & 1u) && g_prof.used < g_prof.cap) {
             slot = g_prof.used++;
-            g_prof.kind[slot] = kind; g_prof.work[slot] = work; g_prof.bytes[slot] = bytes;
+            g_prof.kind[slot] = kind; g_prof.work[slot] = work; g_prof.bytes[slot] = bytes; g_prof.part[slot] = part;
             (void)hipEventRecord(g_prof.ev[2 * slot], st);
         }
     }
@@ -1293,6 +1302,18 @@ int digat_news_project0(const digat_params* p, const float* Xn, float* hpq, int 
 static double g_prof_last_live_fraction = -1.0;
 double digat_profile_live_row_fraction(void) { return g_prof_last_live_fraction; }
 static double g_prof_last_gemm_bytes[DIGAT_KERNEL_KINDS] = {0.0};
+static double g_prof_last_part_ms[XATTN_PARTS] = {0.0}, g_prof_last_part_bytes[XATTN_PARTS] = {0.0};
+static int g_prof_last_part_launches[XATTN_PARTS] = {0};
+// After digat_profile_stop: the DIGAT_KERNEL_XATTN launches by kernel — [0] user graph layers >= 1 (row lists: twin kernel),
+// [1] user graph layer 0 of grouped rows, [2] news graphs in LDS (n <= 16), [3] everything else; ms, algorithmic bytes, launches.
+int digat_profile_xattn_parts(double* ms, double* bytes, int* launches) {
+    for (int p = 0; p < XATTN_PARTS; ++p) {
+        if (ms) ms[p] = g_prof_last_part_ms[p];
+        if (bytes) bytes[p] = g_prof_last_part_bytes[p];
+        if (launches) launches[p] = g_prof_last_part_launches[p];
+    }
+    return DIGAT_OK;
+}
 int digat_profile_gemm_bytes(double* bytes_per_kind) {
     if (!bytes_per_kind) return DIGAT_ERR_ARG;
     for (int k = 0; k < DIGAT_KERNEL_KINDS; ++k) bytes_per_kind[k] = g_prof_last_gemm_bytes[k];
@@ -1332,7 +1353,8 @@ int digat_profile_start(int max_launches) {
     g_prof.kind = (int*)malloc(sizeof(int) * max_launches);
     g_prof.work = (double*)malloc(sizeof(double) * max_launches);
     g_prof.bytes = (double*)malloc(sizeof(double) * max_launches);
-    if (!g_prof.ev || !g_prof.kind || !g_prof.work || !g_prof.bytes) return DIGAT_ERR_ARG;
+    g_prof.part = (int*)malloc(sizeof(int) * max_launches);
+    if (!g_prof.ev || !g_prof.kind || !g_prof.work || !g_prof.bytes || !g_prof.part) return DIGAT_ERR_ARG;
     for (int i = 0; i < 2 * max_launches; ++i)
         if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return DIGAT_ERR_LAUNCH;
     if (hipMalloc((void**)&g_prof.rows_dev, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -1351,6 +1373,7 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         if (launches_per_kind) launches_per_kind[k] = 0;
         g_prof_last_gemm_bytes[k] = 0.0;
     }
+    for (int p = 0; p < XATTN_PARTS; ++p) { g_prof_last_part_ms[p] = 0.0; g_prof_last_part_bytes[p] = 0.0; g_prof_last_part_launches[p] = 0; }
     int rc = DIGAT_OK;
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
@@ -1361,6 +1384,10 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         if (work_per_kind) work_per_kind[k] += g_prof.work[i];
         if (launches_per_kind) launches_per_kind[k] += 1;
         g_prof_last_gemm_bytes[k] += g_prof.bytes[i];
+        if (k == DIGAT_KERNEL_XATTN) {
+            const int p = g_prof.part[i] >= 0 && g_prof.part[i] < XATTN_PARTS ? g_prof.part[i] : XPART_OTHER;
+            g_prof_last_part_ms[p] += ms; g_prof_last_part_bytes[p] += g_prof.work[i]; g_prof_last_part_launches[p] += 1;
+        }
     }
     g_prof_last_live_fraction = -1.0;
     if (g_prof.rows_dev) {
@@ -1370,6 +1397,10 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
                 if (work_per_kind) work_per_kind[k] += (double)rows[k] * g_prof.flops_per_row[k];
                 if (k == DIGAT_KERNEL_PROJ || k == DIGAT_KERNEL_LINEAR) g_prof_last_gemm_bytes[k] += (double)rows[k] * g_prof.bytes_per_row[k];
             }
+            for (int p = 0; p < XATTN_PARTS; ++p) {         // Eq. 8 launches on live-row lists: BYTES counted on the device
+                if (work_per_kind) work_per_kind[DIGAT_KERNEL_XATTN] += (double)rows[8 + p];
+                g_prof_last_part_bytes[p] += (double)rows[8 + p];
+            }
             if (g_prof.rows_nominal[DIGAT_KERNEL_PROJ] > 0)
                 g_prof_last_live_fraction = (double)rows[DIGAT_KERNEL_PROJ] / g_prof.rows_nominal[DIGAT_KERNEL_PROJ];
         }
@@ -1377,8 +1408,8 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
         g_prof.rows_dev = nullptr;
     }
     for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-    free(g_prof.ev); free(g_prof.kind); free(g_prof.work); free(g_prof.bytes);
-    g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.bytes = nullptr; g_prof.cap = g_prof.used = 0;
+    free(g_prof.ev); free(g_prof.kind); free(g_prof.work); free(g_prof.bytes); free(g_prof.part);
+    g_prof.ev = nullptr; g_prof.kind = nullptr; g_prof.work = nullptr; g_prof.bytes = nullptr; g_prof.part = nullptr; g_prof.cap = g_prof.used = 0;
     return rc;
 }
 

@@ -24,6 +24,7 @@ from . import evaluate
 
 
 NEWS_TABLE_MAX_BYTES = 48 << 30     # layer-0 [h|P|Q] tables of news graphs of more than 16 nodes are kept up to this size (288 GB of HBM per GPU)
+NEWS_TABLE_FREE_FRACTION = 0.5      # ... and never beyond this share of the memory that is free when the table is built
 SPARSE_ENTRIES_PER_NODE = 20        # the library's own threshold for DIGAT_XATTN_AUTO (digat_kernels.hip); measured at 15.7 entries per node
                                     # (heavy histories, bench.py): sparse 5.34 vs dense 6.11 ms per 4096-row step; break-even extrapolates to ~21
 
@@ -51,6 +52,9 @@ class DeviceCorpus:
     title_text: Optional[torch.Tensor] = None                # [news_num, Lw] int32 token ids (MIND_corpus.py: news_title_text)
     title_mask: Optional[torch.Tensor] = None                # [news_num, Lw] bool                       (news_title_mask)
     news_key: Optional[tuple] = None                         # the news-encoder weight version news_embedding was computed from
+    xattn_hint: Optional[dict] = None                        # THIS corpus's sparse / dense choice per graph (prepare_news_side); applied to the
+                                                             # encoder whenever this corpus is scored (two corpora may share one encoder)
+    range_overflow_at_prepare: bool = False                  # an fp16x3 GEMM left the format's range while the per-news tables were built
 
     @classmethod
     def from_numpy(cls, corpus, device) -> "DeviceCorpus":
@@ -121,6 +125,7 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
             per_node = float(dc.news_graph.sum(dtype=torch.float64) / (news_num * N))
             hint["news"] = "sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense"
         encoder.corpus_xattn_hint = hint          # in force while the encoder's own setting is "auto"
+        dc.xattn_hint = dict(hint)                # ... and re-applied whenever THIS corpus is scored (apply_corpus_hint)
     if hasattr(encoder, "corpus_activation_max") and dc.news_embedding.numel() > 0:
         # the range of the node features the projections will see ("auto" projection format: graphEncoders.resolved_projection_mode)
         encoder.corpus_activation_max = float(dc.news_embedding.abs().max())
@@ -138,16 +143,29 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
     # scale and at MIND-small stress scale, of 288 — bounded by NEWS_TABLE_MAX_BYTES.
     dc.news_hpq0 = None
     table_bytes = 3 * news_num * N * d * 4
-    big_ok = (N > 16 and table_bytes <= NEWS_TABLE_MAX_BYTES and hasattr(encoder, "resolved_xattn_mode")
+    dev = dc.news_embedding.device
+    budget = NEWS_TABLE_MAX_BYTES
+    if dev.type == "cuda":          # a smaller-HBM part, or a process that also holds training state: stay within what is free
+        budget = min(budget, int(NEWS_TABLE_FREE_FRACTION * torch.cuda.mem_get_info(dev)[0]))
+    # the table holds fp32 P, Q: under the reduced-precision storage modes ("pq-bf16", "pq-fp8": P', Q of news graphs of more than
+    # 16 nodes leave the GEMM epilogue in bf16 / e4m3 at EVERY layer) the in-batch projection stays, so that the configuration
+    # measured is the one documented
+    pq_low = getattr(encoder, "projection_mode", "") in ("pq-bf16", "pq-bf16-x1", "pq-fp8")
+    big_ok = (N > 16 and table_bytes <= budget and hasattr(encoder, "resolved_xattn_mode") and not pq_low
               and encoder.resolved_xattn_mode("news") == "sparse" and news_num < 2 ** 31)
     if (N <= 16 or big_ok) and d % 4 == 0 and d <= 1024 and hasattr(encoder, "project_news_layer0") and getattr(encoder, "graph_depth", 0) > 0:
-        table = torch.empty((3, news_num, N, d), dtype=torch.float32, device=dc.news_embedding.device)
-        chunk = max(batch_size, 4096)
-        with torch.no_grad():
-            for s in range(0, news_num, chunk):
-                e = min(s + chunk, news_num)
-                table[:, s:e] = encoder.project_news_layer0(dc.SA_news_representations[s:e])
-        dc.news_hpq0 = table
+        try:
+            table = torch.empty((3, news_num, N, d), dtype=torch.float32, device=dev)
+            chunk = max(batch_size, 4096)
+            with torch.no_grad():
+                for s in range(0, news_num, chunk):
+                    e = min(s + chunk, news_num)
+                    table[:, s:e] = encoder.project_news_layer0(dc.SA_news_representations[s:e])
+            dc.news_hpq0 = table
+        except torch.OutOfMemoryError:          # the in-batch projection needs no table: slower, same bits
+            table = None
+            dc.news_hpq0 = None
+            torch.cuda.empty_cache()
     # the user graph's layer-0 projections are row-wise: per news (a history node is a news) and per topic node
     dc.user_hpq0 = dc.topic_hpq0 = None
     if hasattr(encoder, "project_user_layer0") and getattr(encoder, "graph_depth", 0) > 0 and d % 4 == 0:
@@ -160,6 +178,18 @@ def prepare_news_side(encoder, dc: DeviceCorpus, batch_size: int) -> None:
         with torch.no_grad():
             dc.ctxq0 = encoder.news_context_queries(dc.c_n0)
     dc.weights_key = weights_key(encoder, dc)
+    # the layer-0 projections of news graphs of more than 16 nodes now run HERE, not during scoring: an activation that leaves the
+    # fp16x3 range while the tables are built must still reach the scoring run's range check (score_rows clears the flag first)
+    dc.range_overflow_at_prepare = bool(hasattr(encoder, "range_overflowed") and encoder.gemm_format() == 1
+                                        and encoder.range_overflowed(reset=False))
+
+
+def apply_corpus_hint(encoder, dc: DeviceCorpus) -> None:
+    """Put THIS corpus's sparse / dense choice (made by ``prepare_news_side``) back in force on the encoder: with two corpora on one
+    encoder (dev and test) the encoder otherwise keeps the hint of whichever was prepared last, and a kept layer-0 table of news
+    graphs of more than 16 nodes would meet an encoder that no longer names the sparse kernel (DIGAT_ERR_ARG) — or the other way."""
+    if dc.xattn_hint is not None and hasattr(encoder, "corpus_xattn_hint"):
+        encoder.corpus_xattn_hint = dict(dc.xattn_hint)
 
 
 def weights_key(encoder, dc: DeviceCorpus) -> tuple:
@@ -170,7 +200,8 @@ def weights_key(encoder, dc: DeviceCorpus) -> tuple:
     fmt = encoder.gemm_format() if hasattr(encoder, "gemm_format") else None
     # ... and the kernel that computes the context-query table (the encoder's pass_rows names it: same bits as inside a pass)
     # ... and whether the news graph's Eq. 8 reads the layer-0 table in place (larger news graphs: only the sparse kernel can)
-    news_mode = getattr(encoder, "news_xattn_mode", None)
+    # — the RESOLVED mode: the explicit setting, or the corpus hint in force (apply_corpus_hint puts the scored corpus's own there)
+    news_mode = encoder.resolved_xattn_mode("news") if hasattr(encoder, "resolved_xattn_mode") else None
     return params + (dc.news_embedding.data_ptr(), dc.news_embedding._version, pm, fmt, getattr(encoder, "pass_rows", 0) >= 2048, news_mode)
 
 
@@ -217,7 +248,11 @@ class GroupedBatchPipeline:
     scored, so at most ``nsets`` batches are in flight: a driver that alternates over n streams wants nsets = n
     (``score_rows`` passes its lane count; with two sets a third lane only overlapped its prologue)."""
 
-    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray, nsets: int = 2, in_place_tables: bool = True):
+    def __init__(self, dc: DeviceCorpus, batches, row_impression_host: np.ndarray, nsets: int = 2, in_place_tables: bool = True,
+                 news_sparse: Optional[bool] = None):
+        """``news_sparse``: whether the encoder's Eq. 8 of the NEWS graph resolves to the sparse kernel at call time — the only
+        reader that can take layer 0 of news graphs of more than 16 nodes from the per-news table; False leaves the table unused
+        (in-batch projection).  None: trust the table's presence (prepare_news_side built it under the sparse mode)."""
         self.dc, self.batches = dc, list(batches)
         self.nsets = nsets = max(2, int(nsets))
         dev = dc.news_embedding.device
@@ -230,7 +265,7 @@ class GroupedBatchPipeline:
 
         import os
         in_place_tables = in_place_tables and os.environ.get("DIGAT_IN_PLACE", "1") != "0"          # A/B switch for measurements
-        in_place = dc.news_hpq0 is not None and d % 4 == 0 and d <= 1024 and in_place_tables
+        in_place = dc.news_hpq0 is not None and d % 4 == 0 and d <= 1024 and in_place_tables and not (N > 16 and news_sparse is False)
         gathered_tables = dc.news_hpq0 is not None and not in_place and N <= 16        # larger news graphs: in place or not at all
 
         def bufs():
@@ -405,13 +440,13 @@ def _pass_rows(batch_size: int, launch_rows: Optional[int] = None) -> int:
     return batch_size * max(1, rows // max(1, batch_size))
 
 
-def range_overflow_any_rank(enc, world_size: int = 1, group=None) -> bool:
+def range_overflow_any_rank(enc, world_size: int = 1, group=None, also: bool = False) -> bool:
     """Has an fp16x3 GEMM of ``enc`` met an activation beyond the format's range since the flag was last cleared — on ANY rank of
     ``group``?  Every rank gets the same answer (MAX all-reduce), so that all of them fall back to bf16x6 together: a per-rank
     decision would all-gather scores of two formats and leave the ranks' caches and weights_key diverged."""
     if not hasattr(enc, "range_overflowed"):
         return False
-    hit = bool(enc.range_overflowed())
+    hit = bool(enc.range_overflowed()) or bool(also)         # `also`: this rank's latch from prepare_news_side (DeviceCorpus.range_overflow_at_prepare)
     if world_size > 1:
         import torch.distributed as dist
         backend = dist.get_backend(group)
@@ -438,11 +473,14 @@ def score_rows(model, dc: DeviceCorpus, start: int, end: int, batch_size: int, g
     ``model.inference`` / ``inference_grouped`` themselves after ``prepare_news_side`` (bench.py's timed loop) must read
     ``graph_encoder.range_overflowed()`` themselves."""
     enc0 = getattr(model, "graph_encoder", None)
+    if enc0 is not None:
+        apply_corpus_hint(enc0, dc)
     watch = check_range and hasattr(enc0, "range_overflowed") and enc0.gemm_format() == 1
     if watch:
         enc0.range_overflowed()            # clear what earlier calls may have left in the flag
     scores = _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_place_tables, launch_rows)
-    if watch and enc0.range_overflowed():
+    # ... or the tables this run read were built from out-of-range activations (the layer-0 GEMMs run in prepare_news_side)
+    if watch and (enc0.range_overflowed() or (dc.range_overflow_at_prepare and enc0.gemm_format() == 1)):
         _range_fallback(enc0, dc, batch_size)
         scores = _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_place_tables, launch_rows)
     return scores
@@ -467,6 +505,8 @@ def _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_pla
     grouped = grouped and hasattr(model, "inference_grouped")
     batches = launch_batches(start, end, batch_size, launch_rows)
     enc = getattr(model, "graph_encoder", None)
+    if enc is not None:
+        apply_corpus_hint(enc, dc)
     if hasattr(enc, "pass_rows") and batches:
         # the launch-set size names the kernel of the [B,d] linears for the whole run (tail set included); per-news tables made
         # under the other name are rebuilt (they hold the same linears' results)
@@ -485,11 +525,13 @@ def _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_pla
 
 def _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables):
     with torch.no_grad():
-        pipe = (GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes), in_place_tables=in_place_tables)
+        enc = getattr(model, "graph_encoder", None)
+        news_sparse = (enc.resolved_xattn_mode("news") == "sparse") if hasattr(enc, "resolved_xattn_mode") else None
+        pipe = (GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes), in_place_tables=in_place_tables,
+                                     news_sparse=news_sparse)
                 if grouped and batches else None)
         # the parameter block (split weights, folded queries) is (re)built on the first lane BEFORE the other lanes are
         # ordered after it: a rebuild inside the loop would run on one lane while the next batch reads it on the other
-        enc = getattr(model, "graph_encoder", None)
         if enc is not None and hasattr(enc, "_params") and batches:
             with torch.cuda.stream(lanes[0]):
                 enc._params()
@@ -548,6 +590,8 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
         model.graph_encoder.range_overflowed()                      # clear what earlier calls may have left in the flag
     if score_fn is None and hasattr(model.graph_encoder, "pass_rows"):
         model.graph_encoder.pass_rows = _pass_rows(batch_size)      # what score_rows will pass per call: names the [B,d] kernel
+    if score_fn is None:
+        apply_corpus_hint(model.graph_encoder, dc)
     if score_fn is None and (dc.c_n0 is None or dc.weights_key != weights_key(model.graph_encoder, dc)):
         prepare_news_side(model.graph_encoder, dc, batch_size)      # first use, or the weights moved on since (an optimizer
                                                                     # step, load_state_dict): the per-news caches are stale
@@ -557,7 +601,7 @@ def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np
     watch_range = score_fn is None and hasattr(enc, "range_overflowed")
     local = score_fn(model, dc, start, end, batch_size) if score_fn else score_rows(model, dc, start, end, batch_size, check_range=False)
     # the fp16x3 range check of score_rows, decided for ALL ranks together (a rank whose shard overflowed must not fall back alone)
-    if watch_range and range_overflow_any_rank(enc, world_size, group):
+    if watch_range and range_overflow_any_rank(enc, world_size, group, also=dc.range_overflow_at_prepare and enc.gemm_format() == 1):
         _range_fallback(enc, dc, batch_size)
         local = score_rows(model, dc, start, end, batch_size, check_range=False)
     if world_size > 1:

@@ -581,6 +581,13 @@ int digat_profile_stop(double* ms_per_kind, double* work_per_kind, int* launches
  * counted) of the recorded launches of the two MFMA kinds, DIGAT_KERNEL_PROJ and DIGAT_KERNEL_LINEAR, whose `work` is flops —
  * for a whole-step roofline (bench.py: roofline_step).  DIGAT_KERNEL_KINDS entries; the byte-priced kinds read 0 here. */
 int digat_profile_gemm_bytes(double* bytes_per_kind);
+/* After digat_profile_stop: the DIGAT_KERNEL_XATTN launches by kernel, DIGAT_XATTN_PARTS entries each (any may be NULL):
+ * [0] user graph, layers >= 1 (row-list launches: xattn_sparse_twin_kernel), [1] user graph, layer 0 of grouped rows
+ * (xattn_sparse_l0_kernel), [2] news graphs of <= 16 nodes with the graph in LDS (xattn_small_lds_kernel), [3] every other
+ * Eq. 8 launch.  ms = summed launch durations, bytes = algorithmic HBM bytes (SURVEY 8d's bytes_B on the live rows: each
+ * distinct row once), launches = count.  Replaces nothing in the reference: measurement only (bench.py roofline_xattn.parts). */
+#define DIGAT_XATTN_PARTS 4
+int digat_profile_xattn_parts(double* ms, double* bytes, int* launches);
 
 #ifdef __cplusplus
 }

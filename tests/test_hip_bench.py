@@ -15,20 +15,51 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _last_json_line(out):
+    """The driver's view: stdout carries exactly ONE JSON line, the last line, small enough for an 8 KB tail."""
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out
+    assert len(lines) == 1 and out.strip().splitlines()[-1] == lines[0], out[-3000:]
+    assert len(lines[0]) < 6000, len(lines[0])
     return json.loads(lines[0])
 
 
-def test_bench_single_gpu_prints_the_contract_line():
+def _detail(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def test_bench_single_gpu_prints_the_contract_line(tmp_path):
+    detail = str(tmp_path / "detail.json")
     cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--impressions", "600", "--news", "2048",
-           "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2", "--e2e-impressions", "1500"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+           "--cpu-rows", "256", "--cpu-seconds", "5", "--extra-steps", "2", "--e2e-impressions", "1500", "--detail", detail]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = _last_json_line(res.stdout)
+    # ---- the compact line alone satisfies the contract (round 4's single 26 KB line did not survive the driver's stdout tail)
+    short = _last_json_line(res.stdout)
+    assert REQUIRED <= set(short) and "cpu_baseline" in short
+    assert short["n_gpus"] == 1 and short["steps"] == 6 and short["warmup"] == 2 and short["value"] > 0
+    assert short["unit"] == "impressions/s" and short["dtype"] == "f32" and short["vs_baseline"] is None and short["valid"] is True
+    assert "AUC-matched" in short["metric"] and "workload" in short["config"] and short["config"]["rows_per_step"] == 4096
+    sroof = short["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(sroof) and 0 < sroof["frac"] < 1
+    assert sroof["traffic"] is None or sroof["traffic"] > 0
+    assert short["cpu_baseline"]["kind"] == "port" and short["cpu_baseline"]["value"] > 0 and short["cpu_baseline"]["cores"] >= 1
+    assert short["auc_match"]["max_abs_metric_diff"] <= short["auc_match"]["tolerance"]
+    assert short["auc_match_trained"]["max_abs_metric_diff"] <= 1e-4
+    assert 0 < short["roofline_xattn"]["frac"] < 1 and 0 < short["roofline_step"]["frac"] < 1
+    assert {"twin", "l0", "news"} <= set(short["roofline_xattn"]["parts"])
+    for part in short["roofline_xattn"]["parts"].values():
+        assert part["us"] > 0 and 0 < part["frac"] < 1 and part["alg_MB"] > 0
+    # one number per extra workload, the oracle check of every extra that scores a different SHAPE, and configs[4]'s verdict
+    sx = short["extra_workloads"]
+    assert all(v == "error" or v["value"] > 0 for v in sx.values()), sx
+    for k in ("mind-small-stress", "mind-large-default", "mind-small-heavy-history"):
+        assert sx[k]["auc_diff"] <= 1e-4, (k, sx[k])
+    assert "pq-bf16" in short["configs4_inference"] and "pq-fp8" in short["configs4_inference"]
+    assert short["detail"]
+    # ---- the full document
+    line = _detail(detail)
     assert REQUIRED <= set(line) and "cpu_baseline" in line
-    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["warmup"] == 2 and line["value"] > 0
-    assert line["unit"] == "impressions/s" and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert abs(line["value"] - short["value"]) <= 1e-3 * line["value"]
     roof = line["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and 0 < roof["frac"] < 1
     cpu = line["cpu_baseline"]
@@ -37,6 +68,12 @@ def test_bench_single_gpu_prints_the_contract_line():
     assert "AUC-matched" in line["metric"]
     rx = line["roofline_xattn"]
     assert rx["bound"] == "hbm" and 0 < rx["frac"] < 1
+    # the three Eq. 8 kernels apart: time alone and in the region, algorithmic bytes (each distinct row once)
+    for name in ("twin", "l0", "news"):
+        e = rx["parts"][name]
+        assert e["launches"] > 0 and e["algorithmic_bytes_per_launch"] > 0 and 0 < e["isolated_frac"] < 1
+    # layer 0 of grouped rows reads each GROUP's rows once: its algorithmic bytes are far below a layer >= 1 launch's
+    assert rx["parts"]["l0"]["algorithmic_bytes_per_launch"] < 0.6 * rx["parts"]["twin"]["isolated_algorithmic_bytes_per_launch"]
     assert line["setup_ms"] > 0 and line["config"]["news_num"] == 2048
     # the same criterion on a model that ranks: trained weights on the planted-signal dev split vs the imported reference's scores
     tr = line["auc_match_trained"]
@@ -61,9 +98,11 @@ def test_bench_single_gpu_prints_the_contract_line():
     # 2 000-impression dev set (the random-click rows of the CPU sample are reported next to it, not asserted: 41 impressions)
     lo = ex["mind-small-default/pq-bf16"]
     assert lo["max_abs_metric_diff_vs_reference_trained_2k"] <= 1e-4 and lo["within_1e-4"] is True
+    # pq-fp8: e4m3 storage of P', Q is OVER the reference's 1e-4 on the trained fixture (measured 1.9e-4): the line says so, the
+    # mode stays opt-in; a silent improvement (or a regression past 3e-4) fails here so that the line's verdict gets rewritten
     f8 = ex["mind-small-default/pq-fp8"]
-    assert f8["max_abs_metric_diff_vs_reference_trained_2k"] <= 3e-4 and f8["ranks_equal_fraction_trained_2k"] > 0.98
-    assert f8["within_1e-4"] == (f8["max_abs_metric_diff_vs_reference_trained_2k"] <= 1e-4)       # printed as measured, opt-in mode
+    assert f8["within_1e-4"] is False and 1e-4 < f8["max_abs_metric_diff_vs_reference_trained_2k"] <= 3e-4
+    assert f8["ranks_equal_fraction_trained_2k"] > 0.98
     assert f8["projection_gemm_result_bytes_per_row"] == 1600 + 2 * 448
     # what the reference's own driver gets from the two-line swap
     di = ex["mind-small-default/drop-in"]
@@ -72,6 +111,9 @@ def test_bench_single_gpu_prints_the_contract_line():
     hv = ex["mind-small-heavy-history"]
     assert hv["adjacency_entries_per_node"] > 12 and hv["live_row_fraction"] > 0.7
     assert hv["auc_match"]["max_abs_metric_diff"] <= 1e-4 and len(hv["user_graph_eq8_variants"]) == 3
+    # configs[2] / configs[3]: the N > 16 news-table path of these extras is held to the oracle in the same line
+    for k in ("mind-small-stress", "mind-large-default"):
+        assert ex[k]["auc_match"]["max_abs_metric_diff"] <= 1e-4 and ex[k]["auc_match"]["rows"] >= 64, ex[k]["auc_match"]
     rs = line["roofline_step"]
     assert 0 < rs["frac"] < 1 and rs["floor_ms"] == max(rs["mfma_floor_ms"], rs["hbm_floor_ms"]) and rs["bound"] in ("hbm", "mfma")
     assert set(line["untimed_seconds_before_the_timed_region"]) == {"prewarm", "lane_tuning"}
