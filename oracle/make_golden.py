@@ -216,18 +216,11 @@ def reference_scores(enc, corpus, batch_size):
     return torch.cat(scores).numpy(), c_n0.numpy()
 
 
-def fixture_devset(ge, ev):
+def fixture_devset(ge, ev, only=None):
     """(iv) synthetic dev sets scored by the reference encoder, ranked by util.py:70-80's rule,
-    metrics by the reference's evaluate.scoring (sklearn AUC)."""
-    specs = {
-        "devset_tiny": synthetic.SynthSpec(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10,
-                                           category_num=5, embedding_dim=64, impressions=200,
-                                           mean_candidates=12.0, max_candidates=40, seed=41),
-        "devset_default": synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24,
-                                              mean_candidates=20.0, max_candidates=60, seed=43),
-    }
-    for tag, spec in specs.items():
-        L = 2 if tag == "devset_tiny" else 3
+    metrics by the reference's evaluate.scoring (sklearn AUC).  Specs: digat_amd.synthetic.DEVSET_FIXTURES."""
+    specs = {tag: (synthetic.SynthSpec(**kw), L) for tag, (kw, L) in synthetic.DEVSET_FIXTURES.items() if only is None or tag in only}
+    for tag, (spec, L) in specs.items():
         corpus = synthetic.make_corpus(spec)
         state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=spec.seed + 1,
                                           bias_std=0.05)
@@ -604,7 +597,8 @@ def main():
     ge, ev = import_reference()
     print("reference imported from", REFERENCE)
     jobs = {"tiny": lambda: fixture_tiny(ge), "edges": lambda: fixture_edges(ge), "train_step": lambda: fixture_train_step(ge),
-            "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev),
+            "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev, ("devset_tiny", "devset_default")),
+            "devset_large": lambda: fixture_devset(ge, ev, ("devset_large",)), "devset_stress": lambda: fixture_devset(ge, ev, ("devset_stress",)),
             "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge),
             "ablation_train": lambda: fixture_ablation_train(ge), "msa": fixture_msa,
             "msa_train": fixture_msa_train,

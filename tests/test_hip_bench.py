@@ -140,7 +140,7 @@ def test_bench_two_ranks_sum_their_rows():
     # SAME (MIND-large) workload, so that nobody divides it by the MIND-small N = 1 headline
     assert line["value"] <= sum(line["per_rank_impressions_per_s"]) * 1.001
     n1 = line["n1_same_workload"]
-    assert n1["value"] > 0 and abs(line["scaling_efficiency"] - line["value"] / (2 * n1["value"])) < 1e-9
+    assert n1["value"] > 0 and abs(line["scaling_efficiency"] - line["value"] / (2 * n1["value"])) < 1e-5      # the compact line rounds its numbers
     assert len(line["devices"]) == 2 and len(line["all_gather_ms_by_rank"]) == 2 and all(v > 0 for v in line["all_gather_ms_by_rank"])
 
 

@@ -283,12 +283,12 @@ def test_cpu_tensors_are_refused():
                                        torch.from_numpy(batch["news_graph_mask"]))
 
 
-DEVSETS = {
-    "devset_tiny.npz": dict(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10, category_num=5,
-                            embedding_dim=64, impressions=200, mean_candidates=12.0, max_candidates=40, seed=41),
-    "devset_default.npz": dict(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24, mean_candidates=20.0,
-                               max_candidates=60, seed=43),
-}
+def _devsets():
+    from digat_amd import synthetic
+    return {k + ".npz": kw for k, (kw, _) in synthetic.DEVSET_FIXTURES.items()}
+
+
+DEVSETS = _devsets()      # devset_tiny / _default, and (round 5) devset_large (N = 26, C = 18) / devset_stress (N = 65, depth 7)
 
 
 @pytest.mark.parametrize("name", sorted(DEVSETS))
@@ -310,6 +310,11 @@ def test_devset_pipeline_scores_ranks_metrics(name):
     model = model.to(_dev()).eval()
     dc = util.DeviceCorpus.from_numpy(corpus, _dev())
     scores, metrics = util.compute_scores(model, dc, 256, labels=corpus.row_label)
+    if spec.news_graph_size > 16:
+        # news graphs of more than 16 nodes: the pipeline must have taken layer 0 from the per-news table, read in place by the
+        # sparse kernel through the candidate ids (round 4's path, until round 5 only compared with other HIP variants)
+        assert model.graph_encoder.resolved_xattn_mode("news") == "sparse" and dc.news_hpq0 is not None
+        assert tuple(dc.news_hpq0.shape) == (3, spec.news_num, spec.news_graph_size, spec.embedding_dim)
     close(dc.c_n0[:64], fx["c_n0_head"], "c_n0")
     close(scores, fx["scores"], "scores", rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(metrics, fx["metrics"], rtol=0, atol=1e-4)      # the repo-stated tolerance
@@ -613,6 +618,45 @@ def test_twin_centres_and_row_chunks_are_bit_identical_to_the_wave_per_centre_ke
                             sa.index_select(0, candt), graphs.index_select(0, candt), masks.index_select(0, candt), c_n0.index_select(0, candt))
     got = with_lists.cpu()[torch.from_numpy(rows)]
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max())), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "permuted", "unused-ids"])
+def test_row_group_need_not_be_contiguous_runs(layout):
+    """``inference_grouped`` takes any ``row_group`` with values in [0, G) (include/digat_hip.h).  The drivers here build runs of
+    consecutive ascending ids, which layer 0's chunk kernel (xattn_sparse_l0_kernel) exploits; for anything else
+    sparse_l0_chunks_kernel makes every row a chunk of one and the list is up to four times longer than the kernel's grid — the
+    waves must stride over it (round-4 advisor finding: half of the layer-0 rows were never written).  Bit-identical to
+    ``inference`` on the expanded tensors for interleaved groups, permuted groups, and G larger than the ids in use."""
+    from digat_amd import synthetic
+    N, H, C, d, L = 10, 50, 17, 400, 3
+    G, per = 24, 36                                   # 4 G <= B: the grouped entry is taken
+    state = synthetic.make_state_dict(d, C, L, seed=301, bias_std=0.05)
+    enc = make_encoder(state, N, H, C, d, L)
+    enc.user_xattn_mode = "sparse"
+    users = to_dev(synthetic.make_encoder_batch(G, N, H, C, d, seed=302, empty_history_rows=(3,)))
+    B = G * per
+    rows = to_dev(synthetic.make_encoder_batch(B, N, H, C, d, seed=303, isolated_news_rows=(5,)))
+    if layout == "interleaved":
+        rg = np.arange(B) % G                         # 0 1 2 ... G-1 0 1 2 ...
+    elif layout == "permuted":
+        rg = np.repeat(np.random.default_rng(7).permutation(G), per)      # runs, but not ascending
+    else:
+        rg = np.repeat(np.arange(G - 6), per + 12)[:B]                    # contiguous ascending runs that end below G - 1
+        assert rg.max() < G - 1 and len(rg) == B
+    rg_t = torch.from_numpy(rg.astype(np.int32)).to(_dev())
+    idx = rg_t.long()
+    with torch.no_grad():
+        c0 = enc.compute_news_graph_context(rows["news_graph_embeddings"], rows["news_graph_mask"])
+        want = enc.inference(rows["news_graph_embeddings"], rows["news_graph"], rows["news_graph_mask"],
+                             users["user_news_embedding"].index_select(0, idx), users["user_graph"].index_select(0, idx),
+                             users["user_category_mask"].index_select(0, idx), users["user_category_indices"].index_select(0, idx), c0)
+        got = enc.inference_grouped(rows["news_graph_embeddings"], rows["news_graph"], rows["news_graph_mask"],
+                                    users["user_news_embedding"], users["user_graph"], users["user_category_mask"],
+                                    users["user_category_indices"], rg_t, c0)
+    torch.cuda.synchronize()
+    for g_, w_, what in zip(got, want, ("news context", "user context")):
+        assert torch.isfinite(g_).all()
+        assert torch.equal(g_, w_), (layout, what, float((g_ - w_).abs().max()))
 
 
 @pytest.mark.parametrize("shape", ["default", "large", "stress"])

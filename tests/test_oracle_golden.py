@@ -119,17 +119,12 @@ def test_train_step_loss_and_gradients():
         close(v.grad.numpy(), fx["g_" + k], "grad " + k)
 
 
-@pytest.mark.parametrize("name", ["devset_tiny.npz", "devset_default.npz"])
+@pytest.mark.parametrize("name", ["devset_tiny.npz", "devset_default.npz", "devset_large.npz", "devset_stress.npz"])
 def test_devset_scores_ranks_metrics(name):
     from digat_amd import synthetic
     fx = load_golden(name)
-    spec = {
-        "devset_tiny.npz": synthetic.SynthSpec(news_num=512, sag_neighbors=3, sag_hops=1, max_history_num=10,
-                                               category_num=5, embedding_dim=64, impressions=200,
-                                               mean_candidates=12.0, max_candidates=40, seed=41),
-        "devset_default.npz": synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=24,
-                                                  mean_candidates=20.0, max_candidates=60, seed=43),
-    }[name]
+    spec = synthetic.SynthSpec(**synthetic.DEVSET_FIXTURES[name[:-4]][0])
+    assert int(fx["depth"]) == synthetic.DEVSET_FIXTURES[name[:-4]][1]
     corpus = synthetic.make_corpus(spec)
     L = int(fx["depth"])
     p = O.as_params(synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L,

@@ -9,11 +9,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 $ROOT/bench.py --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err
 B="python3 $ROOT/bench.py --extra-steps 0 --cpu-rows 0 --steps 30 --e2e-impressions 0"
 # the traced run records its event pairs on EVERY step of the timed region, so that the library's averages and the trace's
 # (tools/trace_region.py, below) are over the same launches
-DIGAT_BENCH_PROFILE_EVERY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_traced.json 2> $OUT/trace.err
+DIGAT_BENCH_PROFILE_EVERY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B --detail $OUT/bench_traced_detail.json > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o t -- $B --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_sq.err
@@ -35,7 +35,7 @@ python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
 python3 tools/trace_region.py $OUT/trace/t_kernel_trace.csv > $OUT/timed_region_kernels.txt 2>&1
 python3 - >> $OUT/timed_region_kernels.txt 2>&1 <<PYEOF
 import json
-j = json.loads(open("$OUT/bench_traced.json").read().strip().splitlines()[-1])
+j = json.load(open("$OUT/bench_traced_detail.json"))
 r, x = j["roofline"], j["roofline_xattn"]
 print()
 print("the same run's own line (library events, sampled steps): ms_per_step %.4f; %s avg_launch_ms %.4f over %d launches; "
