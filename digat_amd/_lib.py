@@ -160,6 +160,7 @@ _SIGNATURES = {
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
     "digat_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "digat_profile_marker": (C.c_int, [C.c_int, _f]),
+    "digat_user_row_runs": (C.c_int, [_f] * 4 + [C.c_int] * 5 + [_f] * 4 + [C.c_size_t, _f]),
     "digat_profile_xattn_parts": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}

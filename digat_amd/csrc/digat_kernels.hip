@@ -141,7 +141,12 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
     }
 }
 
-constexpr int TWIN_R = 4;          // centres with equal adjacency rows served by one wave (user_live_flags_kernel, xattn_sparse_twin_kernel)
+// Round 5: TWO twins per wave at five waves per SIMD (94 registers) instead of four at four (114): 280 against 305 us per 4 096-row
+// launch alone, 460-510 against 535-570 inside the overlapped region (tools/exp/ab.py, alternating runs; three at five waves spill)
+#ifndef DIGAT_TWIN_R
+#define DIGAT_TWIN_R 2
+#endif
+constexpr int TWIN_R = DIGAT_TWIN_R;   // centres with equal adjacency rows served by one wave (user_live_flags_kernel, xattn_sparse_twin_kernel)
 #include "digat_gemm.inc"
 #include "digat_xattn.inc"
 #include "digat_context.inc"
@@ -353,6 +358,22 @@ int digat_gather_tables(const digat_gather_job* jobs, int njobs, void* stream) {
     return DIGAT_OK;
 }
 
+int digat_user_row_runs(const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx, int B, int H, int U, int C1, int d,
+                        int32_t* row_group, int64_t* leaders, int32_t* n_runs, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ue || !Au || !cat_mask || !cat_idx || !row_group || !leaders || !n_runs || !workspace || B <= 0 || H < 0 || U <= 0 || C1 <= 0 || d <= 0)
+        return DIGAT_ERR_ARG;
+    if (d % 4 || ((long)H * d) % 4) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < (size_t)B) return DIGAT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* same = (uint8_t*)workspace;
+    ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)H * d * 4 + (double)U * U + C1 + 8.0 * H), st);
+    hipLaunchKernelGGL(user_rows_same_kernel, dim3(B), dim3(256), 0, st, (const uint4*)ue, Au, cat_mask, cat_idx, B, (long)H * d / 4, U * U, C1, H, same);
+    DIGAT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(user_row_runs_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)same, B, row_group, leaders, n_runs);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
 int digat_split_proj_weights(const float* W, const float* F1, const float* F2, int d, void* wsplit, int format, void* stream) {
     if (!W || !F1 || !F2 || !wsplit || d <= 0) return DIGAT_ERR_ARG;
     return launch_split(W, F1, F2, d, 3, d, wsplit, (hipStream_t)stream, 0, format);
@@ -523,6 +544,11 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 // are two events per layer (a pattern hipGraph capture accepts).  DIGAT_SINGLE_STREAM=1 keeps everything on the
 // caller's stream.
 static size_t l0_chunk_bytes(int B, int U);      // the extra lists of the folded path (defined with the workspace sizes below)
+// group-level outputs of user_live_flags_kernel (grouped entries: at most B / 4 groups), expanded to rows by live_expand_kernel
+static size_t live_group_bytes(int B, int U, int C1) {
+    const size_t Gm = (size_t)B / 4 + 1;
+    return 2 * align_up(Gm * U, 256) + align_up(Gm * U * 4, 256) + align_up(Gm * C1, 256) + 5 * align_up(Gm * 4, 256);
+}
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 // Nothing below is mutable: live-row lists and the side stream are chosen PER CALL through digat_params.flags
 // (DIGAT_PARAMS_NO_LIVE_ROWS, DIGAT_PARAMS_SIDE_STREAM_OFF / _ON), so two host threads with different settings cannot flip each
@@ -575,7 +601,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
                               void* chunk_ws, unsigned char* xsplit_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
-                              const int64_t* news_index, int64_t news_rows, const float* c_n_src) {
+                              const int64_t* news_index, int64_t news_rows, const float* c_n_src, void* live_g_ws = nullptr) {
     // c_n_src: where the news context stands BEFORE layer 0 — c_n itself, or (depth >= 1, context given) the caller's c_n0, read
     // in place by the two consumers that precede the first update instead of being copied into c_n first
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
@@ -704,10 +730,32 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             hipLaunchKernelGGL(sparse_l0_chunks_kernel, dim3(1), dim3(1024), 0, sq, row_group, B, G, SPARSE_L0_ROWS, l0_gs, l0_lead);
             DIGAT_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, Au, cat_mask, cat_idx, B, U, H, C1,
-                           flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2,
-                           twins ? tw_word : (unsigned*)nullptr, twins ? tw_flags : (uint8_t*)nullptr, twins ? tw_cnt : (int*)nullptr);
-        DIGAT_CHECK_LAUNCH();
+        if (live_g_ws && row_group && Au_g && cm_g && ci_g && 4 * (long)G <= B) {
+            // the user side is given per group: the adjacency pass once per GROUP, its results handed to the group's rows
+            const size_t Gm = (size_t)B / 4 + 1;
+            uint8_t* fg = (uint8_t*)live_g_ws;
+            uint8_t* tfg = fg + align_up(Gm * U, 256);
+            unsigned* twg = (unsigned*)(tfg + align_up(Gm * U, 256));
+            uint8_t* bfg = (uint8_t*)twg + align_up(Gm * U * 4, 256);
+            int* cg = (int*)(bfg + align_up(Gm * C1, 256));
+            const size_t gi = align_up(Gm * 4, 256) / 4;
+            int *eg = cg + gi, *hg = eg + gi, *bcg = hg + gi, *tcg = bcg + gi;
+            const bool want_entries = sparse_mode == DIGAT_XATTN_AUTO;
+            hipLaunchKernelGGL(user_live_flags_kernel, dim3((G + 3) / 4), dim3(256), (size_t)4 * ((U * U + 63) & ~63), sq, Au_g, cm_g, ci_g, G, U, H, C1,
+                               fg, cg, want_entries ? eg : (int*)nullptr, hg, bfg, bcg,
+                               twins ? twg : (unsigned*)nullptr, twins ? tfg : (uint8_t*)nullptr, twins ? tcg : (int*)nullptr);
+            DIGAT_CHECK_LAUNCH();
+            const LiveExpand le{fg, twins ? twg : nullptr, tfg, bfg, cg, eg, hg, bcg, tcg,
+                                flags1, twins ? tw_word : nullptr, tw_flags, flags2,
+                                cnt, want_entries ? entries : nullptr, hlast, cnt2, twins ? tw_cnt : nullptr};
+            hipLaunchKernelGGL(live_expand_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, le, row_group, B, U, C1);
+            DIGAT_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * ((U * U + 63) & ~63), sq, Au, cat_mask, cat_idx, B, U, H, C1,
+                               flags1, cnt, sparse_mode == DIGAT_XATTN_AUTO ? entries : (int*)nullptr, hlast, flags2, cnt2,
+                               twins ? tw_word : (unsigned*)nullptr, twins ? tw_flags : (uint8_t*)nullptr, twins ? tw_cnt : (int*)nullptr);
+            DIGAT_CHECK_LAUNCH();
+        }
         if (sparse_mode == DIGAT_XATTN_AUTO) {
             hipLaunchKernelGGL(sparse_decide_kernel, dim3(1), dim3(1024), 0, sq, (const int*)entries, B, U, g_sparse_per_node, flag);
             DIGAT_CHECK_LAUNCH();
@@ -1056,7 +1104,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             void* workspace, size_t workspace_bytes, void* stream, const int* row_group, int G,
                             const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
                             const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr,
-                            const float* ctxq0 = nullptr, const int64_t* news_index = nullptr, int64_t news_rows = 0) {
+                            const float* ctxq0 = nullptr, const int64_t* news_index = nullptr, int64_t news_rows = 0,
+                            void* live_g_ws = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -1131,7 +1180,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
                                   xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, xsplit_ws, Au_g, cm_g, ci_g,
-                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news);
+                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news, live_g_ws);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -1190,7 +1239,7 @@ int digat_encoder_fwd(const digat_params* p, const float* Xn_in, const uint8_t* 
 size_t digat_encoder_grouped_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
     const int U = H + C;
     return digat_encoder_workspace_bytes(B, N, H, C, d, depth) + align_up((size_t)B * U * U, 256)
-           + align_up((size_t)B * (C + 1), 256) + align_up((size_t)B * H * 8, 256);
+           + align_up((size_t)B * (C + 1), 256) + align_up((size_t)B * H * 8, 256) + live_group_bytes(B, U, C + 1);
 }
 
 static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,
@@ -1216,8 +1265,10 @@ static int encoder_fwd_grouped_impl(const digat_params* p, const float* Xn_in, c
         hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, st, jobs, row_group, (long)B);
         DIGAT_CHECK_LAUNCH();
     }
+    void* live_g_ws = ci + align_up((size_t)B * H * 8, 256);
     return encoder_fwd_impl(p, Xn_in, An, Mn, ue_g, Au, cm, (const int64_t*)ci, c_n0, out_news, out_user, B, N, H, workspace,
-                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g, ctxq0, news_index, news_rows);
+                            base, stream, row_group, G, news_hpq0, hist_hpq0, topic_hpq0, Au_g, cat_mask_g, cat_idx_g, ctxq0, news_index, news_rows,
+                            live_g_ws);
 }
 
 int digat_encoder_fwd_grouped(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn,

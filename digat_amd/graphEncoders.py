@@ -132,7 +132,7 @@ class DIGAT(GraphEncoder):
         self.userAttention.initialize()
 
     @contextlib.contextmanager
-    def launch_options(self, side_stream=None, live_rows=None):
+    def launch_options(self, side_stream=None, live_rows=None, shared_users=None):
         """Override ``side_stream`` / ``live_rows`` for the calls the CURRENT THREAD makes inside the block (util.score_rows turns
         the side stream on for single-lane runs this way): another thread driving the same encoder keeps its own settings."""
         table = _TLS.__dict__.setdefault("opts", {})
@@ -144,6 +144,8 @@ class DIGAT(GraphEncoder):
             cur["side_stream"] = side_stream
         if live_rows is not None:
             cur["live_rows"] = bool(live_rows)
+        if shared_users is not None:          # inference(): look for runs of identical consecutive user rows (False: the per-row entry as is)
+            cur["detect_shared_users"] = bool(shared_users)
         table[id(self)] = cur
         try:
             yield self
@@ -541,9 +543,9 @@ class DIGAT(GraphEncoder):
             rg = row_group.long()
             if news_index is not None:
                 Xn = Xn.index_select(0, news_index.long())
-            return self.inference(Xn, news_graph, news_graph_mask, ue.index_select(0, rg), user_graph.index_select(0, rg),
-                                  user_category_mask.index_select(0, rg), user_category_indices.index_select(0, rg),
-                                  news_graph_context)
+            return self._encode(Xn, news_graph, news_graph_mask, ue.index_select(0, rg), user_graph.index_select(0, rg),
+                                user_category_mask.index_select(0, rg), user_category_indices.index_select(0, rg),
+                                news_graph_context)
         An, Mn = _lib.as_bytes(news_graph), _lib.as_bytes(news_graph_mask)
         Au, cm = _lib.as_bytes(user_graph), _lib.as_bytes(user_category_mask)
         ci = user_category_indices.to(torch.int64).contiguous()
@@ -601,8 +603,48 @@ class DIGAT(GraphEncoder):
 
     def inference(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                   user_category_mask, user_category_indices, news_graph_context):
+        """graphEncoders.py:189-198.  The reference's driver expands an impression's user tensors once per candidate
+        (util.py:57-67), so consecutive rows of a dev batch carry bit-identical users: with ``detect_shared_users`` (default) the
+        runs are found on the device (``digat_user_row_runs``: every byte of the four user tensors compared with the previous
+        row's; one host read of the run count) and the batch goes through the grouped entry — layer 0 of the user graph once per
+        impression.  Bit-identical to the per-row path; batches whose rows do not share users (4 runs > rows) take that path."""
+        runs = self._shared_user_runs(news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices)
+        if runs is not None:
+            row_group, leaders = runs
+            return self.inference_grouped(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding.index_select(0, leaders),
+                                          user_graph.index_select(0, leaders), user_category_mask.index_select(0, leaders),
+                                          user_category_indices.index_select(0, leaders), row_group, news_graph_context)
         return self._encode(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                             user_category_mask, user_category_indices, news_graph_context)
+
+    detect_shared_users = True         # inference(): look for runs of identical consecutive user rows (see there)
+    SHARED_USERS_MIN_ROWS = 128        # ... in batches of at least this many rows (below, the pre-pass and its host read cost more than they save)
+
+    def _shared_user_runs(self, Xn, ue, Au, cm, ci):
+        """(row_group [B] int32, leaders [G] int64) when the rows of this batch are runs of identical users worth grouping, else None."""
+        B = ue.shape[0]
+        if (not self._launch_option("detect_shared_users") or self.training or B < self.SHARED_USERS_MIN_ROWS or self.graph_depth == 0
+                or self.resolved_xattn_mode("user") == "dense" or ue.dtype != torch.float32 or not ue.is_cuda
+                or torch.cuda.is_current_stream_capturing()):          # the run count is read on the host: not inside a graph capture
+            return None
+        H, d = self.max_history_num, self.news_embedding_dim
+        U, C1 = self.user_graph_size, self.category_num
+        if tuple(ue.shape) != (B, H, d) or tuple(Au.shape) != (B, U, U) or tuple(cm.shape) != (B, C1) or tuple(ci.shape) != (B, H):
+            return None
+        dev = _lib.require_device(ue, Au, cm, ci)
+        ue_c, Au_b, cm_b = _lib.f32(ue), _lib.as_bytes(Au), _lib.as_bytes(cm)
+        ci_c = ci.to(torch.int64).contiguous()
+        row_group = torch.empty(B, dtype=torch.int32, device=dev)
+        leaders = torch.empty(B, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = _lib.workspace(B, dev, "runs")
+        _lib.check(_lib.lib().digat_user_row_runs(ue_c.data_ptr(), Au_b.data_ptr(), cm_b.data_ptr(), ci_c.data_ptr(), B, H, U, C1, d,
+                                                  row_group.data_ptr(), leaders.data_ptr(), count.data_ptr(), ws.data_ptr(), B,
+                                                  _lib.stream_ptr()), "digat_user_row_runs")
+        G = int(count.item())              # the one host read of the drop-in path
+        if 4 * G > B:
+            return None
+        return row_group, leaders[:G]
 
 
 # ======================================================================================================

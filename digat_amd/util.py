@@ -524,8 +524,13 @@ def _score_rows_once(model, dc, start, end, batch_size, grouped, streams, in_pla
 
 
 def _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables):
+    enc = getattr(model, "graph_encoder", None)
+    if not grouped and hasattr(enc, "launch_options") and enc._launch_option("detect_shared_users"):
+        # grouped=False means the per-row entry as the reference's driver would call it WITHOUT the encoder's own search for
+        # shared users (tests compare the two paths; drivers that want the search call model.inference themselves)
+        with enc.launch_options(shared_users=False):
+            return _score_sets(model, dc, start, batches, scores, lanes, grouped, in_place_tables)
     with torch.no_grad():
-        enc = getattr(model, "graph_encoder", None)
         news_sparse = (enc.resolved_xattn_mode("news") == "sparse") if hasattr(enc, "resolved_xattn_mode") else None
         pipe = (GroupedBatchPipeline(dc, batches, dc.row_impression.cpu().numpy(), nsets=len(lanes), in_place_tables=in_place_tables,
                                      news_sparse=news_sparse)

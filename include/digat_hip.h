@@ -538,6 +538,17 @@ size_t digat_embedding_bwd_workspace_bytes(int64_t M, int dm);
 int digat_embedding_bwd(const float* row_grad, int64_t ld_row_grad, const int32_t* order, const int32_t* sorted_tokens, int64_t M, int dm,
                         float* table_grad, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- runs of identical consecutive user rows (drop-in path) -------------------------------------------------------------------
+ * The reference's driver hands Model.inference the user tensors EXPANDED per row — an impression's history embeddings, user graph,
+ * category mask and indices repeated once per candidate (util.py:57-67, model.py:87-90) — so consecutive rows are bit-identical
+ * runs.  This finds them on the device: row b belongs to the run of row b - 1 iff EVERY byte of its four user tensors is equal
+ * (ue [B,H,d] f32, Au [B,U,U] u8, cat_mask [B,C1] u8, cat_idx [B,H] i64).  row_group[b] = index of row b's run (ascending, runs are
+ * consecutive: the layout digat_encoder_fwd_grouped's layer 0 exploits), leaders[g] = first row of run g (int64), *n_runs = G.
+ * workspace: B bytes.  DIGAT.inference reads *n_runs (one host synchronisation), gathers the leaders' user tensors and calls the
+ * grouped entry when 4 G <= B: bit-identical to digat_encoder_fwd on the expanded rows. */
+int digat_user_row_runs(const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx, int B, int H, int U, int C1, int d,
+                        int32_t* row_group, int64_t* leaders, int32_t* n_runs, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- batch assembly (the device-side counterpart of MIND_dataset.py's __getitem__ + collate) ------------------
  * All table gathers of one scoring batch in one launch.  Job k copies `rows` rows of `row_bytes` bytes: dst row r = src row
  * idx[r] (idx2 == NULL, inner = 1) or src row idx2[idx[r / inner] * inner + r % inner] (two-level: e.g. the representation of

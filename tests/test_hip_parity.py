@@ -620,6 +620,50 @@ def test_twin_centres_and_row_chunks_are_bit_identical_to_the_wave_per_centre_ke
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max())), float((got - want).abs().max())
 
 
+def test_inference_finds_shared_users_by_itself():
+    """Round 5, the drop-in path: the reference's driver expands an impression's user tensors once per candidate (util.py:57-67), so
+    ``DIGAT.inference`` looks for runs of identical consecutive user rows (digat_user_row_runs: every byte of the four user tensors)
+    and takes the grouped entry.  Same bits as the per-row entry; the run structure it finds equals numpy's; a batch whose rows
+    do not share users, a batch with ONE differing float in the middle of a run, and a graph capture all take the right path."""
+    from digat_amd import synthetic
+    N, H, C, d, L = 10, 50, 17, 400, 3
+    sizes = [1, 37, 2, 60, 5, 41, 33, 9, 50, 18]                       # candidates per impression
+    G, B = len(sizes), sum(sizes)
+    state = synthetic.make_state_dict(d, C, L, seed=311, bias_std=0.05)
+    enc = make_encoder(state, N, H, C, d, L)
+    enc.corpus_xattn_hint = {"user": "sparse"}
+    users = to_dev(synthetic.make_encoder_batch(G, N, H, C, d, seed=312, empty_history_rows=(2,)))
+    rows = to_dev(synthetic.make_encoder_batch(B, N, H, C, d, seed=313))
+    rg = np.repeat(np.arange(G), sizes)
+    idx = torch.from_numpy(rg).to(_dev())
+    ukeys = ("user_news_embedding", "user_graph", "user_category_mask", "user_category_indices")
+    exp = {k: users[k].index_select(0, idx).contiguous() for k in ukeys}
+    with torch.no_grad():
+        c0 = enc.compute_news_graph_context(rows["news_graph_embeddings"], rows["news_graph_mask"])
+        runs = enc._shared_user_runs(rows["news_graph_embeddings"], *(exp[k] for k in ukeys))
+        assert runs is not None
+        assert np.array_equal(runs[0].cpu().numpy(), rg) and np.array_equal(runs[1].cpu().numpy(), np.r_[0, np.cumsum(sizes)[:-1]])
+        args = (rows["news_graph_embeddings"], rows["news_graph"], rows["news_graph_mask"], *(exp[k] for k in ukeys), c0)
+        found = enc.inference(*args)
+        with enc.launch_options(shared_users=False):
+            per_row = enc.inference(*args)
+        for a, b in zip(found, per_row):
+            assert torch.equal(a, b), float((a - b).abs().max())
+        # one float changed inside a run splits it in two (G + 1 runs: the changed row starts a run, the row after it another)
+        ue2 = exp["user_news_embedding"].clone()
+        b_mid = int(np.cumsum(sizes)[3] - 20)
+        ue2[b_mid, 0, d - 1] += 1.0                                        # history slot 0: a live node of this user
+        runs2 = enc._shared_user_runs(rows["news_graph_embeddings"], ue2, *(exp[k] for k in ukeys[1:]))
+        assert runs2 is not None and runs2[1].numel() == G + 2 and b_mid in runs2[1].tolist() and b_mid + 1 in runs2[1].tolist()
+        found2 = enc.inference(args[0], args[1], args[2], ue2, *args[4:])
+        with enc.launch_options(shared_users=False):
+            per_row2 = enc.inference(args[0], args[1], args[2], ue2, *args[4:])
+        assert torch.equal(found2[1], per_row2[1]) and not torch.equal(found2[1][b_mid], found[1][b_mid])
+        # rows that do not share users: the per-row entry
+        assert enc._shared_user_runs(rows["news_graph_embeddings"], *(rows[k] for k in ukeys)) is None
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("layout", ["interleaved", "permuted", "unused-ids"])
 def test_row_group_need_not_be_contiguous_runs(layout):
     """``inference_grouped`` takes any ``row_group`` with values in [0, G) (include/digat_hip.h).  The drivers here build runs of
@@ -633,6 +677,7 @@ def test_row_group_need_not_be_contiguous_runs(layout):
     state = synthetic.make_state_dict(d, C, L, seed=301, bias_std=0.05)
     enc = make_encoder(state, N, H, C, d, L)
     enc.user_xattn_mode = "sparse"
+    enc.detect_shared_users = False                   # `inference` below is the per-row reference: no search for shared users
     users = to_dev(synthetic.make_encoder_batch(G, N, H, C, d, seed=302, empty_history_rows=(3,)))
     B = G * per
     rows = to_dev(synthetic.make_encoder_batch(B, N, H, C, d, seed=303, isolated_news_rows=(5,)))
