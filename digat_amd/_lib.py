@@ -189,10 +189,42 @@ def lib() -> C.CDLL:
     return _lib
 
 
+EXT_PATH = os.path.join(_HERE, "lib", "digat_torch_ext.so")
+USE_TORCH_EXT = os.environ.get("DIGAT_TORCH_EXT", "1") != "0"     # 0: bind the hot entry points through ctypes too (A/B, tests)
+_ext = None
+
+
+def ext():
+    """The thin torch extension over the same C ABI (csrc/digat_torch_ext.cpp: tensors in, raw pointers + the current HIP stream
+    out), or None when it has not been built or is switched off — the ctypes table above then binds the same entry points.  A
+    different library build named by DIGAT_HIP_LIB is only reachable through ctypes (the extension is linked to lib/libdigat_hip.so)."""
+    global _ext
+    if not USE_TORCH_EXT or os.environ.get("DIGAT_HIP_LIB"):
+        return None
+    if _ext is None:
+        if not os.path.exists(EXT_PATH):
+            _ext = False
+        else:
+            import importlib.util
+            lib()                                   # libdigat_hip.so first: the extension's rpath finds the same file
+            spec = importlib.util.spec_from_file_location("digat_torch_ext", EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != lib().digat_version():
+                raise DigatHipError("digat_torch_ext.so and libdigat_hip.so disagree about the ABI version: rebuild (python -m digat_amd.build)")
+            _ext = mod
+    return _ext or None
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib().digat_error_string(code).decode()
         raise DigatHipError(f"{what} failed: [{code}] {msg}")
+
+
+def addressof(struct) -> int:
+    """Address of a ctypes structure (the parameter block handed to the torch extension as an integer)."""
+    return C.addressof(struct)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -477,6 +477,10 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
+        X = _lib.ext()
+        if X is not None:         # the thin torch extension: tensors in, the same C entry point behind it
+            X.encoder_fwd(_lib.addressof(P), Xn, An, Mn, ue, Au, cm, ci, c0, out_n, out_u, ws)
+            return out_n, out_u
         _lib.check(L.digat_encoder_fwd(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
                                        cm.data_ptr(), ci.data_ptr(), _lib.ptr(c0), out_n.data_ptr(), out_u.data_ptr(),
                                        B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_encoder_fwd")
@@ -557,8 +561,9 @@ class DIGAT(GraphEncoder):
         nbytes = L.digat_encoder_grouped_workspace_bytes(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
+        X = _lib.ext()
+        hpq = hh = th = cq = ni = None
         if news_hpq0 is not None or hist_hpq0 is not None or ctxq0 is not None or news_index is not None:
-            hpq = hh = th = cq = ni = None
             M = 0
             if news_index is not None:
                 if news_hpq0 is None or news_graph_context is None:
@@ -579,12 +584,18 @@ class DIGAT(GraphEncoder):
                 hh, th = _lib.f32(hist_hpq0), _lib.f32(topic_hpq0)
                 if tuple(hh.shape) != (3, G, H, d) or tuple(th.shape) != (3, C, d):
                     raise ValueError("hist_hpq0 must be [3, G, H, d] and topic_hpq0 [3, C, d] (project_user_layer0)")
+            if X is not None:
+                X.encoder_fwd_grouped(_lib.addressof(P), Xn, An, Mn, ue, Au, cm, ci, rg, c0, hpq, hh, th, cq, ni, out_n, out_u, ws)
+                return out_n, out_u
             _lib.check(L.digat_encoder_fwd_grouped_cached(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(),
                                                           Au.data_ptr(), cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(),
                                                           _lib.ptr(hpq), _lib.ptr(hh), _lib.ptr(th), _lib.ptr(cq), _lib.ptr(ni), M,
                                                           out_n.data_ptr(),
                                                           out_u.data_ptr(), B, G, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()),
                        "digat_encoder_fwd_grouped_cached")
+            return out_n, out_u
+        if X is not None:
+            X.encoder_fwd_grouped(_lib.addressof(P), Xn, An, Mn, ue, Au, cm, ci, rg, c0, None, None, None, None, None, out_n, out_u, ws)
             return out_n, out_u
         _lib.check(L.digat_encoder_fwd_grouped(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
                                                cm.data_ptr(), ci.data_ptr(), rg.data_ptr(), c0.data_ptr(), out_n.data_ptr(),
@@ -638,9 +649,13 @@ class DIGAT(GraphEncoder):
         leaders = torch.empty(B, dtype=torch.int64, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
         ws = _lib.workspace(B, dev, "runs")
-        _lib.check(_lib.lib().digat_user_row_runs(ue_c.data_ptr(), Au_b.data_ptr(), cm_b.data_ptr(), ci_c.data_ptr(), B, H, U, C1, d,
-                                                  row_group.data_ptr(), leaders.data_ptr(), count.data_ptr(), ws.data_ptr(), B,
-                                                  _lib.stream_ptr()), "digat_user_row_runs")
+        X = _lib.ext()
+        if X is not None:
+            X.user_row_runs(ue_c, Au_b, cm_b, ci_c, row_group, leaders, count, ws)
+        else:
+            _lib.check(_lib.lib().digat_user_row_runs(ue_c.data_ptr(), Au_b.data_ptr(), cm_b.data_ptr(), ci_c.data_ptr(), B, H, U, C1, d,
+                                                      row_group.data_ptr(), leaders.data_ptr(), count.data_ptr(), ws.data_ptr(), B,
+                                                      _lib.stream_ptr()), "digat_user_row_runs")
         G = int(count.item())              # the one host read of the drop-in path
         if 4 * G > B:
             return None

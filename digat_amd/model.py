@@ -13,6 +13,17 @@ import torch.nn as nn
 from . import _lib, graphEncoders, newsEncoders
 
 
+def _row_logits(news_rep, user_rep, logits):
+    """model.py:75,90: logits = sum_d(user_ctx * news_ctx), one wave per row (digat_row_logits)."""
+    X = _lib.ext()
+    if X is not None:
+        X.row_logits(news_rep, user_rep, logits)
+        return
+    B, d = news_rep.shape
+    _lib.check(_lib.lib().digat_row_logits(news_rep.data_ptr(), user_rep.data_ptr(), logits.data_ptr(), B, d, _lib.stream_ptr()),
+               "digat_row_logits")
+
+
 class Model(nn.Module):
     def __init__(self, config, news_encoder: nn.Module = None):
         super().__init__()
@@ -79,8 +90,7 @@ class Model(nn.Module):
         B, d = news_rep.shape
         logits = torch.empty(B, dtype=torch.float32, device=news_rep.device)
         if B:
-            _lib.check(_lib.lib().digat_row_logits(news_rep.data_ptr(), user_rep.data_ptr(), logits.data_ptr(), B, d,
-                                                   _lib.stream_ptr()), "digat_row_logits")
+            _row_logits(news_rep, user_rep, logits)
         return logits
 
 
@@ -97,8 +107,7 @@ class Model(nn.Module):
         B, d = news_rep.shape
         logits = torch.empty(B, dtype=torch.float32, device=news_rep.device)
         if B:
-            _lib.check(_lib.lib().digat_row_logits(news_rep.data_ptr(), user_rep.data_ptr(), logits.data_ptr(), B, d,
-                                                   _lib.stream_ptr()), "digat_row_logits")
+            _row_logits(news_rep, user_rep, logits)
         return logits
 
 

@@ -32,6 +32,23 @@ def test_header_symbols_are_exported():
     assert b"workspace" in L.digat_error_string(3)
 
 
+def test_torch_extension_is_built_and_binds_the_same_library():
+    """The thin torch extension over the C ABI (csrc/digat_torch_ext.cpp; BASELINE north_star's binding): built in-tree next to
+    libdigat_hip.so, importable without a GPU, same ABI version, and it refuses CPU tensors (no compute call is made here)."""
+    from digat_amd import _lib, build
+    build.build(verbose=False)
+    assert os.path.exists(_lib.EXT_PATH)
+    X = _lib.ext()
+    assert X is not None and X.abi_version() == _lib.lib().digat_version()
+    assert {"encoder_fwd", "encoder_fwd_grouped", "row_logits", "user_row_runs"} <= set(dir(X))
+    with pytest.raises(RuntimeError):
+        X.row_logits(torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2))
+    # the extension is host code only: every kernel lives in libdigat_hip.so, which it links by rpath
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _lib.EXT_PATH], capture_output=True, text=True).stdout
+    assert "libdigat_hip.so" in needed and "$ORIGIN" in needed
+
+
 def test_workspace_queries():
     from digat_amd import _lib
     L = _lib.lib()

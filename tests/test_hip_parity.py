@@ -620,6 +620,53 @@ def test_twin_centres_and_row_chunks_are_bit_identical_to_the_wave_per_centre_ke
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max())), float((got - want).abs().max())
 
 
+def test_torch_extension_and_ctypes_bindings_agree():
+    """The two bindings of the C ABI — the thin torch extension (digat_torch_ext.so, the default) and the ctypes table — reach the
+    same entry points with the same arguments: forward, inference, inference_grouped (plain and with per-news tables) and the logits
+    give the same bits, and the extension rejects what the ABI does not take (a non-contiguous tensor, a wrong dtype)."""
+    from digat_amd import _lib, synthetic, util
+    from digat_amd.model import Model, PrecomputedNewsEncoder
+    assert _lib.ext() is not None, "digat_torch_ext.so has not been built (python -m digat_amd.build)"
+    spec = synthetic.SynthSpec(news_num=1024, sag_neighbors=3, sag_hops=2, impressions=30, mean_candidates=30.0, max_candidates=80, seed=91)
+    corpus = synthetic.make_corpus(spec)
+    L = 2
+    state = synthetic.make_state_dict(spec.embedding_dim, spec.category_num, L, seed=92, bias_std=0.05)
+    cfg = types.SimpleNamespace(news_encoder="MSA", graph_encoder="DIGAT", news_graph_size=spec.news_graph_size,
+                                max_history_num=spec.max_history_num, category_num=spec.category_num, graph_depth=L, dropout_rate=0.2)
+    model = Model(cfg, news_encoder=PrecomputedNewsEncoder(torch.from_numpy(corpus.news_embedding)))
+    model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(_dev()).eval()
+    dc = util.DeviceCorpus.from_numpy(corpus, _dev())
+    util.prepare_news_side(model.graph_encoder, dc, 512)
+    enc = model.graph_encoder
+    batch = to_dev(synthetic.make_encoder_batch(96, spec.news_graph_size, spec.max_history_num, spec.category_num, spec.embedding_dim, seed=93))
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph", "user_category_mask",
+            "user_category_indices")
+
+    def run():
+        with torch.no_grad():
+            out = list(enc(*(batch[k] for k in keys)))
+            out.append(util.score_rows(model, dc, 0, dc.rows, 512))                      # grouped, per-news tables in place
+            out.append(util.score_rows(model, dc, 0, dc.rows, 512, grouped=False))       # per-row entry
+        torch.cuda.synchronize()
+        return out
+    via_ext = run()
+    _lib.USE_TORCH_EXT = False
+    try:
+        assert _lib.ext() is None
+        via_ctypes = run()
+    finally:
+        _lib.USE_TORCH_EXT = True
+    for a, b in zip(via_ext, via_ctypes):
+        assert torch.equal(a, b)
+    X = _lib.ext()
+    good = torch.zeros((8, 400), device=_dev())
+    with pytest.raises(RuntimeError):
+        X.row_logits(good, good.t().contiguous().t(), torch.zeros(8, device=_dev()))     # not contiguous
+    with pytest.raises(RuntimeError):
+        X.row_logits(good, good.double(), torch.zeros(8, device=_dev()))                 # not float32
+
+
 def test_inference_finds_shared_users_by_itself():
     """Round 5, the drop-in path: the reference's driver expands an impression's user tensors once per candidate (util.py:57-67), so
     ``DIGAT.inference`` looks for runs of identical consecutive user rows (digat_user_row_runs: every byte of the four user tensors)
