@@ -160,6 +160,8 @@ _SIGNATURES = {
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
     "digat_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "digat_profile_marker": (C.c_int, [C.c_int, _f]),
+    "digat_encoder_shared_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "digat_encoder_fwd_shared": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_user_row_runs": (C.c_int, [_f] * 4 + [C.c_int] * 5 + [_f] * 4 + [C.c_size_t, _f]),
     "digat_profile_xattn_parts": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -601,7 +601,14 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               float* r_news, int* live_ws, hipStream_t st, const int* row_group, int G, const float* ue_groups,
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
                               void* chunk_ws, unsigned char* xsplit_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
-                              const int64_t* news_index, int64_t news_rows, const float* c_n_src, void* live_g_ws = nullptr) {
+                              const int64_t* news_index, int64_t news_rows, const float* c_n_src, void* live_g_ws = nullptr,
+                              const uint8_t* run_leader = nullptr, const uint8_t* run_lead = nullptr) {
+    // SHARED-USER RUNS (digat_encoder_fwd_shared; round 5): the user tensors are given per ROW, as the reference's driver hands them
+    // over (util.py:57-67), and consecutive rows with identical users were found on the device: row_group[b] = the ROW that leads
+    // row b's run, run_leader[b] = 1 for those rows, run_lead[b] = rows of the layer-0 chunk row b leads.  Layer 0's group-level
+    // data (user nodes, [h|P|Q], live flags) then lives in the LEADING ROW's slots of the full-size buffers, every count stays on
+    // the device (no host read of the number of runs), and the group-indexed kernels work as they are.  G is not used.
+    const bool shared = run_leader != nullptr && run_lead != nullptr && row_group != nullptr;
     // c_n_src: where the news context stands BEFORE layer 0 — c_n itself, or (depth >= 1, context given) the caller's c_n0, read
     // in place by the two consumers that precede the first update instead of being copied into c_n first
     const bool xu0_grouped = Xg0 != nullptr;       // layer-0 user nodes exist once per group, at Xg0 [G,U,d]
@@ -690,12 +697,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     // layer 0 of grouped rows on the chunk kernel (R rows of an impression per wave: xattn_sparse_l0_kernel): its list — the live
     // centres of the rows that lead a chunk — is made with the other two
     static const int l0_chunks_on = LAB_ENV("DIGAT_L0_CHUNKS", 1);
-    const bool l0_chunked = l0_chunks_on && chunk_ws && row_group && Xg0 && want_live && g_l0_live_on && !use_staged &&
+    const bool l0_chunked = l0_chunks_on && chunk_ws && row_group && (Xg0 || shared) && want_live && g_l0_live_on && !use_staged &&
                             sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 128 && U <= 128;
     int* const l0_gs = (int*)chunk_ws;
     int* const l0_off = l0_gs + align_up((size_t)B + 64, 64);
-    uint8_t* const l0_lead = (uint8_t*)(l0_off + align_up((size_t)B + 64, 64));
-    int* const l0_idx = (int*)(l0_lead + align_up((size_t)B, 256));
+    uint8_t* const l0_lead_own = (uint8_t*)(l0_off + align_up((size_t)B + 64, 64));
+    const uint8_t* const l0_lead = shared ? run_lead : l0_lead_own;          // shared runs: the chunk sizes came with the runs
+    int* const l0_idx = (int*)(l0_lead_own + align_up((size_t)B, 256));
     // twins: centres of a graph with equal adjacency rows, served together in layers >= 1 (xattn_sparse_twin_kernel)
     static const int twins_on = LAB_ENV("DIGAT_SPARSE_TWINS", 1);
     const bool twins = twins_on && chunk_ws && want_live && !use_staged && sparse_mode == DIGAT_XATTN_SPARSE && d / 4 <= 128 && U <= 128 && L > 1;
@@ -704,6 +712,9 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     uint8_t* const tw_flags = (uint8_t*)tw_list + align_up((size_t)B * U * 4, 256);
     int* const tw_cnt = (int*)(tw_flags + align_up((size_t)B * U, 256));
     int* const tw_off = tw_cnt + align_up((size_t)B + 64, 64);
+    // shared runs: the live nodes of the LEADING rows (the rows layer 0's group projection has to make), offsets [B + 64] + list [B U]
+    int* const gl_off = tw_off + align_up((size_t)B + 64, 64);
+    int* const gl_idx = gl_off + align_up((size_t)B + 64, 64);
     TwinLists tw_pub{nullptr, nullptr, nullptr};
     // Node rows between two layers also as ready-split fp16 pairs (fp16x3 format, sparse Eq. 8 on the live lists): the Eq. 8 kernel of
     // layer i stores them, the projection GEMM of layer i + 1 reads its A fragments as they are (GemmArgs.a_split; same bits)
@@ -726,11 +737,24 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         uint8_t* flags1 = (uint8_t*)(hlast + align_up((size_t)B, 64));
         uint8_t* flags2 = flags1 + align_up((size_t)B * U, 256);
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)U * U + 2.0 * C1 + H * 8.0) + (double)B * (U + C1) * 6, sq);
-        if (l0_chunked) {
-            hipLaunchKernelGGL(sparse_l0_chunks_kernel, dim3(1), dim3(1024), 0, sq, row_group, B, G, SPARSE_L0_ROWS, l0_gs, l0_lead);
+        if (l0_chunked && !shared) {
+            hipLaunchKernelGGL(sparse_l0_chunks_kernel, dim3(1), dim3(1024), 0, sq, row_group, B, G, SPARSE_L0_ROWS, l0_gs, l0_lead_own);
             DIGAT_CHECK_LAUNCH();
         }
-        if (live_g_ws && row_group && Au_g && cm_g && ci_g && 4 * (long)G <= B) {
+        if (shared) {
+            // the adjacency pass for the leading rows only; every other row takes its leader's results (in place)
+            const bool want_entries = sparse_mode == DIGAT_XATTN_AUTO;
+            hipLaunchKernelGGL(user_live_flags_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * ((U * U + 63) & ~63), sq, Au, cat_mask, cat_idx, B, U, H, C1,
+                               flags1, cnt, want_entries ? entries : (int*)nullptr, hlast, flags2, cnt2,
+                               twins ? tw_word : (unsigned*)nullptr, twins ? tw_flags : (uint8_t*)nullptr, twins ? tw_cnt : (int*)nullptr,
+                               run_leader);
+            DIGAT_CHECK_LAUNCH();
+            const LiveExpand le{flags1, twins ? tw_word : nullptr, tw_flags, flags2, cnt, entries, hlast, cnt2, tw_cnt,
+                                flags1, twins ? tw_word : nullptr, tw_flags, flags2,
+                                cnt, want_entries ? entries : nullptr, hlast, cnt2, twins ? tw_cnt : nullptr};
+            hipLaunchKernelGGL(live_expand_kernel, dim3((B + 3) / 4), dim3(256), 0, sq, le, row_group, B, U, C1);
+            DIGAT_CHECK_LAUNCH();
+        } else if (live_g_ws && row_group && Au_g && cm_g && ci_g && 4 * (long)G <= B) {
             // the user side is given per group: the adjacency pass once per GROUP, its results handed to the group's rows
             const size_t Gm = (size_t)B / 4 + 1;
             uint8_t* fg = (uint8_t*)live_g_ws;
@@ -763,8 +787,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         }
         // node list and bucket list: both scans in one launch, both lists in one launch
         // up to four lists in the two launches: live nodes, live buckets, [layer-0 chunk leads | twin leads] as wanted
-        ScanPair sp{{cnt, cnt2, nullptr, nullptr}, {off, off2, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-        ListPair lp{{flags1, flags2, nullptr, nullptr}, {off, off2, nullptr, nullptr}, {U, C1, U, U}, {idx, idx2, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        ScanPair sp{{cnt, cnt2}, {off, off2}, {nullptr, nullptr}};
+        ListPair lp{{flags1, flags2}, {off, off2}, {U, C1, U, U, U, U}, {idx, idx2}, {nullptr, nullptr}};
         int jobs = 2;
         if (l0_chunked) {
             sp.cnt[jobs] = cnt; sp.off[jobs] = l0_off; sp.rowmask[jobs] = l0_lead;
@@ -774,6 +798,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         if (twins) {
             sp.cnt[jobs] = tw_cnt; sp.off[jobs] = tw_off;
             lp.flags[jobs] = tw_flags; lp.off[jobs] = tw_off; lp.out[jobs] = tw_list;
+            lp.width[jobs] = U;
+            ++jobs;
+        }
+        if (shared) {            // the live nodes of the leading rows: what layer 0's group projection makes
+            sp.cnt[jobs] = cnt; sp.off[jobs] = gl_off; sp.rowmask[jobs] = run_leader;
+            lp.flags[jobs] = flags1; lp.off[jobs] = gl_off; lp.out[jobs] = gl_idx; lp.rowmask[jobs] = run_leader;
+            lp.width[jobs] = U;
             ++jobs;
         }
         hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(jobs), dim3(1024), 0, sq, sp, B);
@@ -824,6 +855,22 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     // stay in L2); only P' = K3_b + P depends on the row and is expanded later.  Needs nothing but the inputs.
     auto group_project = [&](hipStream_t sq) -> int {
         const digat_layer_params& lu = p->user[0];
+        if (shared) {
+            // shared runs: [h|P|Q] of the LEADING rows' live nodes, in place in the full-size planes (the per-row launch of layer 0
+            // restricted to the rows whose results anybody reads; K3 joins in the Eq. 8 kernel, as for the groups below)
+            const size_t ndf = (size_t)B * U * d;
+            float* hs = (float*)xws;
+            GemmArgs gs = gemm_plain(Xu[0], d, lu.W, lu.bW, hs, d, B * U, d, d, 0);
+            gs.w[1] = lu.F1; gs.bias[1] = nullptr; gs.y[1] = hs + ndf;
+            gs.w[2] = lu.F2; gs.bias[2] = nullptr; gs.y[2] = hs + 2 * ndf;
+            gs.nsegs = 3;
+            gs.x3_segs = pq_x3 ? 6 : 0;
+            gs.wsplit = (const unsigned short*)lu.wsplit;
+            gs.format = fmt; gs.range_flag = rflag;
+            gs.m_dispatch = B * U;
+            if (want_live && gemm_is_bf16x6(gs)) { gs.rowidx = gl_idx; gs.nrows_dev = gl_off + B; }
+            return launch_gemm(gs, sq, DIGAT_KERNEL_PROJ);
+        }
         const size_t ndg = (size_t)G * U * d;
         const size_t nd = (size_t)B * U * d;
         float* Xg = xu0_grouped ? const_cast<float*>(Xg0) : Xu[1];     // group nodes: built by the caller, or here (Xu[1] is free until layer 0 writes it)
@@ -902,7 +949,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         rc = from_c_n(0, st);
         if (rc) return rc;
     }
-    rc = user_ctx_tail(xu0_grouped ? Xg0 : Xu[0], nullptr, st, xu0_grouped ? row_group : nullptr, nullptr,
+    const bool xu0_shared = shared && sparse_mode == DIGAT_XATTN_SPARSE;      // only the leading rows of Xu[0] were built: read through row_group
+    rc = user_ctx_tail(xu0_grouped ? Xg0 : Xu[0], nullptr, st, (xu0_grouped || xu0_shared) ? row_group : nullptr, nullptr,
                        ctxq0 ? ctxq0 : nullptr, ctxq0 ? ctxq0 + bd : nullptr);        // c_u (:192)
     if (rc) return rc;
     const float* xn_cur = Xn_in;
@@ -938,8 +986,8 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
         // test_uninitialised_workspace_cannot_reach_the_outputs fills the scratch with NaN patterns).
         if (i == 0 && want_live) publish_live_rows();
         if (i == 0 && row_group) {
-            const size_t ndg = (size_t)G * U * d;
             const size_t nd = (size_t)B * U * d;
+            const size_t ndg = shared ? nd : (size_t)G * U * d;      // shared runs: full-size planes, a group's rows sit in its leading row's slots
             float* h0 = (float*)xws;
             float* P0 = h0 + ndg;
             float* P = h0 + nd;
@@ -955,13 +1003,13 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                 // (opt-in) keep the older arrangement: every centre computed, and the dead rows of the other buffer filled with X_i
                 const bool l0_live = want_live && live_flags && !use_staged && g_l0_live_on;
                 SparseArgs sg{P0, Q0, h0, xu0_grouped ? Xg0 : Xu[0], lu.a, Au, Xu[1], r_user, row_group, l0_live ? live_flags : nullptr,
-                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, xu0_grouped ? 1 : 0,
+                                    sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, U, d / 4, (xu0_grouped || xu0_shared) ? 1 : 0,
                                     (!l0_live && xu0_grouped && want_live) ? (const uint8_t*)pend_flags : nullptr, Xu[0],
                                     l0_live ? rowidx : nullptr, l0_live ? nrows_dev : nullptr, G, nullptr, 0, 0};
                 if (presplit && l0_live && L > 1) { sg.xsplit = xsplit_ws; sg.xsplit_range = rflag; xs_ready = true; }
                 if (l0_chunked && l0_live && sparse_l0_ok(sg)) {
                     // R rows of an impression per wave: every neighbour row fetched serves R rows (xattn_sparse_l0_kernel; same bits)
-                    rc = launch_sparse_l0(sg, l0_lead, l0_idx, l0_off + B, G, st);
+                    rc = launch_sparse_l0(sg, l0_lead, l0_idx, l0_off + B, shared ? (B + SPARSE_L0_ROWS - 1) / SPARSE_L0_ROWS : G, st);
                 } else
                 rc = use_staged ? launch_staged(sg, plan, 0, 0, st) : launch_sparse(sg, st);
             }
@@ -1068,9 +1116,11 @@ static size_t xsplit_bytes(int, int, int) { return 0; }
 // and list [B U] int of the live centres of the chunk-leading rows
 // + twins (xattn_sparse_twin_kernel): twin words [B U] u32, lead flags [B U] bytes, leads per row [B + 64] int, offsets [B + 64] int, list [B U] int
 // + [B] int: the candidate ids as 32-bit indices (layer 0 of larger news graphs from the per-news tables)
+// + shared-user runs (digat_encoder_fwd_shared): offsets [B + 64] int and list [B U] int of the live nodes of the run-leading rows
 static size_t l0_chunk_bytes(int B, int U) {
     return 2 * align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B, 256) + align_up((size_t)B * U * 4, 256)
            + 2 * align_up((size_t)B * U * 4, 256) + align_up((size_t)B * U, 256) + 2 * align_up((size_t)(B + 64) * 4, 256)
+           + align_up((size_t)(B + 64) * 4, 256) + align_up((size_t)B * U * 4, 256)
            + align_up((size_t)B * 4, 256);
 }
 
@@ -1105,7 +1155,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
                             const float* news_hpq0 = nullptr, const float* hist_hpq0 = nullptr, const float* topic_hpq0 = nullptr,
                             const uint8_t* Au_g = nullptr, const uint8_t* cm_g = nullptr, const int64_t* ci_g = nullptr,
                             const float* ctxq0 = nullptr, const int64_t* news_index = nullptr, int64_t news_rows = 0,
-                            void* live_g_ws = nullptr) {
+                            void* live_g_ws = nullptr, const uint8_t* run_leader = nullptr, const uint8_t* run_lead = nullptr) {
     if (!p || !Xn_in || !An || !Mn || !ue || !Au || !cat_mask || !cat_idx || !out_news || !out_user || !workspace)
         return DIGAT_ERR_ARG;
     if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
@@ -1152,7 +1202,12 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     // Rows of one impression share the user nodes.  When every reader of the layer-0 nodes can go through the group index
     // (the sparse Eq. 8 kernel and the topic pooling can; the dense tile / aggregation kernels cannot) they are built once
     // per GROUP: 3 MB instead of a 110 MB expansion that the first two kernels would read back.
-    const bool xu0_grouped = folded && row_group && L > 0 && (p->flags & 3) == DIGAT_XATTN_SPARSE && d / 4 <= 256 && U > 16 && 3 * (long)G <= B;
+    // Shared-user runs (digat_encoder_fwd_shared): ue is per ROW, row_group[b] = the row that leads row b's run.  Taken when the
+    // group-indexed kernels of layer 0 apply (sparse Eq. 8 on the live lists); otherwise the runs are ignored: the plain per-row path.
+    const bool shared = run_leader && run_lead && row_group && folded && L > 0 && (p->flags & 3) == DIGAT_XATTN_SPARSE &&
+                        !(p->flags & DIGAT_PARAMS_NO_LIVE_ROWS) && d / 4 <= 128 && U <= 128 && U > 16;
+    if ((run_leader || run_lead) && !shared) { row_group = nullptr; G = 0; run_leader = run_lead = nullptr; }
+    const bool xu0_grouped = !shared && folded && row_group && L > 0 && (p->flags & 3) == DIGAT_XATTN_SPARSE && d / 4 <= 256 && U > 16 && 3 * (long)G <= B;
     // user graph nodes = [history | topic nodes]  (:191)
     float* const Xg0 = xu0_grouped ? (float*)xws + 2 * (size_t)G * U * d : nullptr;      // behind the groups' h and P in the h slot (3 G <= B)
     {
@@ -1161,9 +1216,10 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         ProfScope prof(DIGAT_KERNEL_GLUE, (double)nrows * ((double)H * d * 8 + (double)C * d * 4), st);
+        // shared runs: ue is per row already, and only the run-leading rows are ever read (through row_group)
         hipLaunchKernelGGL(build_user_nodes_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ue,
                            (const float4*)p->topic_node_embedding, (float4*)(xu0_grouped ? Xg0 : Xu[0]), nrows, H, C, d / 4,
-                           xu0_grouped ? (const int*)nullptr : row_group);
+                           (xu0_grouped || shared) ? (const int*)nullptr : row_group, shared ? run_leader : (const uint8_t*)nullptr);
         DIGAT_CHECK_LAUNCH();
     }
     // c_n: given (inference, :189) or computed (forward, :180); it lives in out_news from here on
@@ -1180,7 +1236,8 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     if (folded)
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
                                   xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, xsplit_ws, Au_g, cm_g, ci_g,
-                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news, live_g_ws);
+                                  c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news, live_g_ws,
+                                  run_leader, run_lead);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,
@@ -1290,6 +1347,39 @@ int digat_encoder_fwd_grouped_cached(const digat_params* p, const float* Xn_in, 
     if (ctxq0 && !c_n0) return DIGAT_ERR_ARG;           // the queries belong to a given news context
     return encoder_fwd_grouped_impl(p, Xn_in, An, Mn, ue_g, Au_g, cat_mask_g, cat_idx_g, row_group, c_n0, out_news, out_user, B, G, N, H,
                                     workspace, workspace_bytes, stream, news_hpq0, hist_hpq0, topic_hpq0, ctxq0, news_index, news_rows);
+}
+
+// ---- shared-user runs: the per-row signature of digat_encoder_fwd, the grouped arithmetic of layer 0 --------------------------
+size_t digat_encoder_shared_workspace_bytes(int B, int N, int H, int C, int d, int depth) {
+    // + same[B] bytes, leader_of[B] int, is_leader[B] bytes, lead[B] bytes
+    return digat_encoder_workspace_bytes(B, N, H, C, d, depth) + 3 * align_up((size_t)B, 256) + align_up((size_t)B * 4, 256);
+}
+
+int digat_encoder_fwd_shared(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn, const float* ue,
+                             const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n0, float* out_news,
+                             float* out_user, int B, int N, int H, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !ue || !Au || !cat_mask || !cat_idx || !workspace) return DIGAT_ERR_ARG;
+    if (B < 0 || N <= 0 || H < 0) return DIGAT_ERR_ARG;
+    const int d = p->d, C = p->category_num, U = H + C;
+    if (d <= 0 || d % 4 || C < 0) return DIGAT_ERR_SHAPE;
+    if (workspace_bytes < digat_encoder_shared_workspace_bytes(B, N, H, C, d, p->depth)) return DIGAT_ERR_WORKSPACE;
+    if (B == 0) return DIGAT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t base = digat_encoder_workspace_bytes(B, N, H, C, d, p->depth);
+    uint8_t* same = (uint8_t*)workspace + base;
+    uint8_t* is_leader = same + align_up((size_t)B, 256);
+    uint8_t* lead = is_leader + align_up((size_t)B, 256);
+    int* leader_of = (int*)(lead + align_up((size_t)B, 256));
+    {
+        ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)H * d * 4 + (double)U * U + (C + 1) + 8.0 * H), st);
+        hipLaunchKernelGGL(user_rows_same_kernel, dim3(B), dim3(256), 0, st, (const uint4*)ue, Au, cat_mask, cat_idx, B, (long)H * d / 4, U * U,
+                           C + 1, H, same);
+        DIGAT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(shared_runs_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)same, B, SPARSE_L0_ROWS, leader_of, is_leader, lead);
+        DIGAT_CHECK_LAUNCH();
+    }
+    return encoder_fwd_impl(p, Xn_in, An, Mn, ue, Au, cat_mask, cat_idx, c_n0, out_news, out_user, B, N, H, workspace, base, stream,
+                            leader_of, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, is_leader, lead);
 }
 
 int digat_news_context_queries(const digat_params* p, const float* c_n, float* out, int M, void* stream) {

@@ -56,20 +56,22 @@ const digat_params* params_at(int64_t addr) {
     return reinterpret_cast<const digat_params*>(static_cast<uintptr_t>(addr));
 }
 
-// graphEncoders.DIGAT.forward (c_n0 undefined) / .inference (c_n0 given): digat_encoder_fwd
-void encoder_fwd(int64_t params, const at::Tensor& Xn, const at::Tensor& An, const at::Tensor& Mn, const at::Tensor& ue, const at::Tensor& Au,
+// graphEncoders.DIGAT.forward (c_n0 undefined) / .inference (c_n0 given): digat_encoder_fwd, or — shared = true — digat_encoder_fwd_shared
+// (the same arguments; runs of identical consecutive user rows are found on the device and layer 0 is computed once per run)
+void encoder_fwd(int64_t params, bool shared, const at::Tensor& Xn, const at::Tensor& An, const at::Tensor& Mn, const at::Tensor& ue, const at::Tensor& Au,
                  const at::Tensor& cm, const at::Tensor& ci, const c10::optional<at::Tensor>& c_n0, at::Tensor& out_n, at::Tensor& out_u,
                  at::Tensor& ws) {
     need(Xn.dim() == 3 && ue.dim() == 3, "news_graph_embeddings [B,N,d] and user_news_embedding [B,H,d] expected");
     const int B = (int)Xn.size(0), N = (int)Xn.size(1), H = (int)ue.size(1);
     need(ue.size(0) == B && An.size(0) == B && Mn.size(0) == B && Au.size(0) == B && cm.size(0) == B && ci.size(0) == B, "batch sizes differ");
     need(out_n.size(0) == B && out_u.size(0) == B && out_n.size(1) == Xn.size(2) && out_u.size(1) == Xn.size(2), "outputs must be [B,d]");
-    check(digat_encoder_fwd(params_at(params), f32(Xn, Xn, "news_graph_embeddings"), bytes(An, Xn, "news_graph"), bytes(Mn, Xn, "news_graph_mask"),
-                            f32(ue, Xn, "user_news_embedding"), bytes(Au, Xn, "user_graph"), bytes(cm, Xn, "user_category_mask"),
-                            i64(ci, Xn, "user_category_indices"), c_n0.has_value() ? f32(*c_n0, Xn, "news_graph_context") : nullptr,
-                            const_cast<float*>(f32(out_n, Xn, "out_news")), const_cast<float*>(f32(out_u, Xn, "out_user")), B, N, H,
-                            on_gpu(ws, Xn, "workspace").data_ptr(), (size_t)ws.nbytes(), stream_of(Xn)),
-          "digat_encoder_fwd");
+    const auto fn = shared ? digat_encoder_fwd_shared : digat_encoder_fwd;
+    check(fn(params_at(params), f32(Xn, Xn, "news_graph_embeddings"), bytes(An, Xn, "news_graph"), bytes(Mn, Xn, "news_graph_mask"),
+             f32(ue, Xn, "user_news_embedding"), bytes(Au, Xn, "user_graph"), bytes(cm, Xn, "user_category_mask"),
+             i64(ci, Xn, "user_category_indices"), c_n0.has_value() ? f32(*c_n0, Xn, "news_graph_context") : nullptr,
+             const_cast<float*>(f32(out_n, Xn, "out_news")), const_cast<float*>(f32(out_u, Xn, "out_user")), B, N, H,
+             on_gpu(ws, Xn, "workspace").data_ptr(), (size_t)ws.nbytes(), stream_of(Xn)),
+          shared ? "digat_encoder_fwd_shared" : "digat_encoder_fwd");
 }
 
 // DIGAT.inference_grouped: digat_encoder_fwd_grouped / _grouped_cached (the per-news tables are optional, any subset)

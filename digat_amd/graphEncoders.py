@@ -457,7 +457,7 @@ class DIGAT(GraphEncoder):
 
     # ------------------------------------------------------------------ a5 (graphEncoders.py:177-198)
     def _encode(self, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
-                user_category_mask, user_category_indices, news_graph_context):
+                user_category_mask, user_category_indices, news_graph_context, shared: bool = False):
         Xn, ue = _lib.f32(news_graph_embeddings), _lib.f32(user_news_embedding)
         dev = _lib.require_device(Xn, news_graph, news_graph_mask, ue, user_graph, user_category_mask,
                                   user_category_indices)
@@ -474,16 +474,18 @@ class DIGAT(GraphEncoder):
         if B == 0:                       # empty tensors have no storage to point at
             return out_n, out_u
         L = _lib.lib()
-        nbytes = L.digat_encoder_workspace_bytes(B, N, H, C, d, self.graph_depth)
+        # shared: digat_encoder_fwd_shared — the same arguments, runs of identical consecutive user rows found on the device
+        nbytes = (L.digat_encoder_shared_workspace_bytes if shared else L.digat_encoder_workspace_bytes)(B, N, H, C, d, self.graph_depth)
         ws = _lib.workspace(nbytes, dev, "encoder")
         P = self._params()
         X = _lib.ext()
         if X is not None:         # the thin torch extension: tensors in, the same C entry point behind it
-            X.encoder_fwd(_lib.addressof(P), Xn, An, Mn, ue, Au, cm, ci, c0, out_n, out_u, ws)
+            X.encoder_fwd(_lib.addressof(P), bool(shared), Xn, An, Mn, ue, Au, cm, ci, c0, out_n, out_u, ws)
             return out_n, out_u
-        _lib.check(L.digat_encoder_fwd(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
-                                       cm.data_ptr(), ci.data_ptr(), _lib.ptr(c0), out_n.data_ptr(), out_u.data_ptr(),
-                                       B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), "digat_encoder_fwd")
+        fn, what = (L.digat_encoder_fwd_shared, "digat_encoder_fwd_shared") if shared else (L.digat_encoder_fwd, "digat_encoder_fwd")
+        _lib.check(fn(P, Xn.data_ptr(), An.data_ptr(), Mn.data_ptr(), ue.data_ptr(), Au.data_ptr(),
+                      cm.data_ptr(), ci.data_ptr(), _lib.ptr(c0), out_n.data_ptr(), out_u.data_ptr(),
+                      B, N, H, ws.data_ptr(), nbytes, _lib.stream_ptr()), what)
         return out_n, out_u
 
     def project_news_layer0(self, news_graph_embeddings):
@@ -616,23 +618,30 @@ class DIGAT(GraphEncoder):
                   user_category_mask, user_category_indices, news_graph_context):
         """graphEncoders.py:189-198.  The reference's driver expands an impression's user tensors once per candidate
         (util.py:57-67), so consecutive rows of a dev batch carry bit-identical users: with ``detect_shared_users`` (default) the
-        runs are found on the device (``digat_user_row_runs``: every byte of the four user tensors compared with the previous
-        row's; one host read of the run count) and the batch goes through the grouped entry — layer 0 of the user graph once per
-        impression.  Bit-identical to the per-row path; batches whose rows do not share users (4 runs > rows) take that path."""
-        runs = self._shared_user_runs(news_graph_embeddings, user_news_embedding, user_graph, user_category_mask, user_category_indices)
-        if runs is not None:
-            row_group, leaders = runs
-            return self.inference_grouped(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding.index_select(0, leaders),
-                                          user_graph.index_select(0, leaders), user_category_mask.index_select(0, leaders),
-                                          user_category_indices.index_select(0, leaders), row_group, news_graph_context)
+        call goes to ``digat_encoder_fwd_shared`` — the runs are found on the device (every byte of the four user tensors compared
+        with the previous row's), nothing is read back by the host, and layer 0 of the user graph is computed once per run.
+        Bit-identical to the per-row entry; rows that share nothing cost the comparison pass on top of it."""
+        want = bool(self._launch_option("detect_shared_users") and not self.training and self.graph_depth > 0
+                    and news_graph_embeddings.shape[0] >= self.SHARED_USERS_MIN_ROWS)
+        if (want and self.user_xattn_mode == "auto" and "user" not in self.corpus_xattn_hint and user_graph.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            # a driver that never showed the corpus to util.prepare_news_side (the reference's own loop): the sparse / dense choice
+            # of the user graph's Eq. 8 is made here, ONCE, from the first batch (one host read; the library's per-batch device-side
+            # choice launches both variants, and only the sparse one can share layer 0 between the rows of a run)
+            from .util import SPARSE_ENTRIES_PER_NODE
+            per_node = float(user_graph.sum(dtype=torch.float64) / max(1, user_graph.shape[0] * user_graph.shape[1]))
+            self.corpus_xattn_hint = dict(self.corpus_xattn_hint, user="sparse" if per_node <= SPARSE_ENTRIES_PER_NODE else "dense")
+        shared = want and self.resolved_xattn_mode("user") == "sparse"
         return self._encode(news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
-                            user_category_mask, user_category_indices, news_graph_context)
+                            user_category_mask, user_category_indices, news_graph_context, shared=shared)
 
     detect_shared_users = True         # inference(): look for runs of identical consecutive user rows (see there)
-    SHARED_USERS_MIN_ROWS = 128        # ... in batches of at least this many rows (below, the pre-pass and its host read cost more than they save)
+    SHARED_USERS_MIN_ROWS = 128        # ... in batches of at least this many rows
 
     def _shared_user_runs(self, Xn, ue, Au, cm, ci):
-        """(row_group [B] int32, leaders [G] int64) when the rows of this batch are runs of identical users worth grouping, else None."""
+        """(row_group [B] int32, leaders [G] int64) when the rows of this batch are runs of identical users worth grouping, else None:
+        the search of ``digat_encoder_fwd_shared`` as a stand-alone call (``digat_user_row_runs``; one host read of the run count) for
+        drivers that want to call ``inference_grouped`` themselves, and for the tests."""
         B = ue.shape[0]
         if (not self._launch_option("detect_shared_users") or self.training or B < self.SHARED_USERS_MIN_ROWS or self.graph_depth == 0
                 or self.resolved_xattn_mode("user") == "dense" or ue.dtype != torch.float32 or not ue.is_cuda

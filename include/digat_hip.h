@@ -549,6 +549,18 @@ int digat_embedding_bwd(const float* row_grad, int64_t ld_row_grad, const int32_
 int digat_user_row_runs(const float* ue, const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx, int B, int H, int U, int C1, int d,
                         int32_t* row_group, int64_t* leaders, int32_t* n_runs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* digat_encoder_fwd with the search for shared users INSIDE (DIGAT.inference's default; round 5): the same per-row arguments as
+ * digat_encoder_fwd (graphEncoders.py:189-198) — the reference's driver expands an impression's user tensors once per candidate
+ * (util.py:57-67) — and layer 0 of the user graph computed once per RUN of identical consecutive rows: the runs are found on the
+ * device (every byte of the four user tensors compared with the previous row's), every count stays there (no host read), the
+ * group-level data of a run lives in its leading row's slots of the full-size buffers.  Bit-identical to digat_encoder_fwd; rows
+ * that share nothing cost the comparison pass (B x 85 KB read once) on top of it.  Needs the folded inference path and the sparse
+ * Eq. 8 variant of the user graph (flags), else it IS digat_encoder_fwd.  c_n0 may be NULL (forward). */
+size_t digat_encoder_shared_workspace_bytes(int B, int N, int H, int C, int d, int depth);
+int digat_encoder_fwd_shared(const digat_params* p, const float* Xn_in, const uint8_t* An, const uint8_t* Mn, const float* ue,
+                             const uint8_t* Au, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n0, float* out_news,
+                             float* out_user, int B, int N, int H, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- batch assembly (the device-side counterpart of MIND_dataset.py's __getitem__ + collate) ------------------
  * All table gathers of one scoring batch in one launch.  Job k copies `rows` rows of `row_bytes` bytes: dst row r = src row
  * idx[r] (idx2 == NULL, inner = 1) or src row idx2[idx[r / inner] * inner + r % inner] (two-level: e.g. the representation of
