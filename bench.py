@@ -482,7 +482,7 @@ def run_training(W, args, D: Dist, steps, warmup):
         nonlocal k
         idx = (np.arange(64) + 64 * (k % nb)) % len(ts)
         k += 1
-        return tr.train_step(idx)
+        return tr.train_step(idx, read_loss=False)       # the loss stays on the device (Trainer.train sums it there and reads it per epoch)
     # pre-warm (clocks, allocator, code objects): by the clock on one rank; with more ranks every step is a collective (DDP's
     # gradient all-reduce), so every rank must take the SAME number of them — a per-rank clock would leave one rank waiting forever
     if D.world == 1:
@@ -537,7 +537,7 @@ def run_training(W, args, D: Dist, steps, warmup):
             ddp["bucket_sizes_bytes"] = str(log.get("bucket_sizes", ""))
         except Exception as exc:          # the logging API is private: report, never fail the run
             ddp = {"error": repr(exc)}
-    return types.SimpleNamespace(elapsed=elapsed, rows_done=steps * 64 * 5, loss=loss, roofline=roof, ddp=ddp)
+    return types.SimpleNamespace(elapsed=elapsed, rows_done=steps * 64 * 5, loss=float(loss.item()), roofline=roof, ddp=ddp)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

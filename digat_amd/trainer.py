@@ -149,7 +149,12 @@ class Trainer:
                 dc.news_graph.index_select(0, news.flatten()).view(B, K, *dc.news_graph.shape[1:]),
                 dc.news_graph_mask.index_select(0, news.flatten()).view(B, K, -1))
 
-    def train_step(self, idx: np.ndarray) -> float:
+    def train_step(self, idx: np.ndarray, read_loss: bool = True):
+        """One optimisation step (trainer.py:98-105).  ``read_loss`` (default): return the loss as a Python float, as the reference's
+        loop reads it every step (``loss.item()``: a host synchronisation per step, which serialises the host's enqueue of the next
+        step with the device's work on this one); False: return the loss TENSOR (detached, on the device) and read nothing — the
+        caller sums on the device and reads once per epoch (``Trainer.train``), and the step after this one is enqueued while the
+        device is still busy."""
         logits = self.model(*self.gather(idx))                          # [B, 1+neg]
         loss = training_loss(logits)
         self.optimizer.zero_grad()
@@ -157,7 +162,7 @@ class Trainer:
         if self.gradient_clip_norm > 0:
             nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip_norm)
         self.optimizer.step()
-        return float(loss.item())
+        return float(loss.item()) if read_loss else loss.detach()
 
     def _criterion(self, metrics):
         """trainer.py:121-165: the value the best epoch is chosen by (``>=`` keeps the later of two equal epochs)."""
@@ -196,16 +201,20 @@ class Trainer:
             if e == self.decay_epoch:
                 self.lr_decay()
             self.model.train()
-            epoch_loss, nb = 0.0, 0
+            # the epoch's loss is summed ON THE DEVICE (float64: the sum of the same fp32 losses the reference adds up as Python floats,
+            # trainer.py:105) and read once at the end: the reference's per-step loss.item() drains the device every step
+            epoch_loss_dev, nb = torch.zeros((), dtype=torch.float64, device=self.dc.news_embedding.device), 0
             for idx in self.batches(e):
-                loss = self.train_step(idx)
-                epoch_loss += loss
+                log_now = bool(log_every and self.is_main_rank and (step + 1) % log_every == 0)
+                loss = self.train_step(idx, read_loss=False)
+                epoch_loss_dev += loss.double()
                 nb += 1
                 step += 1
-                if log_every and self.is_main_rank and step % log_every == 0:
-                    print(f"epoch {e} step {step} loss {loss:.4f}", flush=True)
+                if log_now:
+                    print(f"epoch {e} step {step} loss {float(loss.item()):.4f}", flush=True)
                 if max_steps is not None and step >= max_steps:
                     break
+            epoch_loss = float(epoch_loss_dev.item())
             self.losses.append(epoch_loss / max(nb, 1))
             if self.is_main_rank:
                 print(f"Epoch {e} : train done\nloss = {self.losses[-1]}", flush=True)

@@ -365,7 +365,10 @@ class XattnFused(Function):
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX, dc = torch.empty_like(Xd), torch.empty_like(cvec)
-        dW, dF1, dF2, dF3 = (torch.empty_like(W) for _ in range(4))
+        # dW, dF1, dF2 as the three blocks of one [3 d, d] buffer: the library writes its single [3 d, d] weight-gradient product in place
+        dW3 = torch.empty((3,) + tuple(W.shape), dtype=torch.float32, device=dev)
+        dW, dF1, dF2 = dW3[0], dW3[1], dW3[2]
+        dF3 = torch.empty_like(W)
         dbW, db3, da = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
         _lib.check(L().digat_xattn_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(),
                                        F1.data_ptr(), F2.data_ptr(), F3.data_ptr(), a.data_ptr(), ctx.p, save.data_ptr(), nsave,
