@@ -37,6 +37,16 @@ def main():
         rows_per_step = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])["config"]["rows_per_step"]
     except (OSError, ValueError, KeyError, IndexError):
         pass
+    # issue-side counters of the same command (pmc_sq / pmc_mfma passes): how busy the vector ALUs were and how long waves sat
+    # waiting — the Eq. 8 kernels are bound there, not by bytes (VALU busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES: quad-cycles of
+    # VALU activity summed over the four SIMDs of a CU x 4 / (4 SIMDs x busy CU cycles))
+    sq = {n: counters(os.path.join(src, d), n) for d, names in (("pmc_sq", ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU")),
+                                                                ("pmc_mfma", ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")))
+          for n in names}
+
+    def mean(name, k):
+        v = sq.get(name, {}).get(k, [])
+        return sum(v) / len(v) if v else None
     summary = {}
     for k in sorted(set(fetch) | set(write)):
         fk, wk = fetch.get(k, []), write.get(k, [])
@@ -49,6 +59,13 @@ def main():
             "hbm_bytes_mean": (2 * sum(fk) / len(fk) + sum(wk) / len(wk)) * 1024,
             "hbm_bytes_max_launch": (2 * max(fk) + max(wk)) * 1024,
         }
+        wc, wa, av, bc, mf = (mean(n, k) for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"))
+        if wc and wa is not None:
+            summary[k]["wait_fraction_of_wave_cycles"] = wa / wc
+        if bc and av is not None:
+            summary[k]["valu_busy_fraction"] = av / bc
+        if bc and mf:
+            summary[k]["mfma_busy_fraction"] = mf / (4.0 * bc)
     json.dump({"unit_note": "FETCH_SIZE/WRITE_SIZE in KB per launch; hbm_bytes = (2*FETCH + WRITE)*1024 "
                             "(gfx950 half-count correction on wide reads, MI355X_MICROARCH.md §HBM)",
                "rows_per_step": rows_per_step, "kernels": summary}, open(out + "_pmc.json", "w"), indent=1)
