@@ -101,19 +101,40 @@ __device__ __forceinline__ float dpp_mov(float v) {
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// Round 5: the four row sums S0..S3 meet by two more DPP steps instead of four v_readlane + two v_mov + three v_add on uniform
+// values (9 vector instructions -> 3; the Eq. 8 kernels are vector-issue-bound and reduce once per (centre, neighbour) pair):
+// row_bcast:15 adds lane 15 of row k to every lane of row k + 1 (rows 1 and 3: S0 + S1, S2 + S3), row_bcast:31 adds lane 31
+// (= S0 + S1) to rows 2 and 3, so lane 63 holds (S3 + S2) + (S1 + S0) — THE BITS of the old (S0 + S1) + (S2 + S3): float + is
+// commutative, the association is the same.  Disabled rows keep their value (row_mask).  The s_nop's are the DPP read-after-write
+// wait states hipcc would insert itself for a builtin (inline asm is not padded: cdna_hip_programming.md section 5.7).
+#ifndef DIGAT_WAVE_REDUCE_BCAST
+#define DIGAT_WAVE_REDUCE_BCAST 1
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);      // row_half_mirror
     v += dpp_mov<0x140>(v);      // row_mirror: every lane holds the sum of its row of 16
+#if DIGAT_WAVE_REDUCE_BCAST
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return lane_bcast(v, 63);
+#else
     return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0xB1>(v));
     v = fmaxf(v, dpp_mov<0x4E>(v));
     v = fmaxf(v, dpp_mov<0x141>(v));
     v = fmaxf(v, dpp_mov<0x140>(v));
+#if DIGAT_WAVE_REDUCE_BCAST
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return lane_bcast(v, 63);
+#else
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+#endif
 }
 
 // one 16-byte-per-lane global -> LDS copy; LDS address = lds_byte_addr (wave-uniform) + 16*lane.
@@ -146,6 +167,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
 #ifndef DIGAT_TWIN_R
 #define DIGAT_TWIN_R 2
 #endif
+// leaky_relu(0.2) of a WAVE-UNIFORM score (a wave_sum result): e > 0 ? e : 0.2 e = max(e, 0.2 e), bit for bit (also for -0, inf, NaN),
+// as one multiply and one v_max_f32 with the score as the scalar operand (fmaxf costs a third instruction that canonicalises e)
+__device__ __forceinline__ float leaky02_uniform(float e) {
+    const float t = 0.2f * e;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(e), "v"(t));
+    return r;
+}
 constexpr int TWIN_R = DIGAT_TWIN_R;   // centres with equal adjacency rows served by one wave (user_live_flags_kernel, xattn_sparse_twin_kernel)
 #include "digat_gemm.inc"
 #include "digat_xattn.inc"
