@@ -615,7 +615,12 @@ static SideStream* side_stream(hipStream_t caller) {
     Entry& e = tab[used++];
     e.dev = dev; e.caller = caller;
     SideStream& x = e.side;
-    const bool ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+    // LAB builds: DIGAT_SIDE_PRIO=1 makes the side stream a high-priority queue (its small news-side kernels are dispatched ahead of the
+    // caller stream's long-running Eq. 8 / GEMM workgroups whenever a slot frees up)
+    static const int side_prio = LAB_ENV("DIGAT_SIDE_PRIO", 0);
+    int prio_lo = 0, prio_hi = 0;
+    if (side_prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const bool ok = (side_prio ? hipStreamCreateWithPriority(&x.s, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking)) == hipSuccess &&
                     hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&x.early, hipEventDisableTiming) == hipSuccess;

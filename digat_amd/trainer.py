@@ -92,7 +92,12 @@ class Trainer:
         _lib.lib().digat_set_train_precision(1 if self.train_precision == "bf16" else 0)
         self.epochs = config.epoch
         self.batch_size = config.batch_size
-        self.optimizer = optim.Adam(parameter_groups(self.model, getattr(config, "weight_decay", 0.0)), lr=config.lr)
+        # the reference's Adam (trainer.py:30), as ONE fused launch per parameter group on the GPU: the default multi-tensor form walks
+        # every parameter ten times (the synthetic news table alone is 104 MB: 0.63 ms of a 7.1 ms step, 20 launches); the update is
+        # the same arithmetic per element
+        groups = parameter_groups(self.model, getattr(config, "weight_decay", 0.0))
+        on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+        self.optimizer = optim.Adam(groups, lr=config.lr, **({"fused": True} if on_gpu and getattr(config, "fused_adam", True) else {}))
         self.gradient_clip_norm = getattr(config, "gradient_clip_norm", 1.0)
         self.decay_epoch = lr_decay_epoch(self.epochs)
         self.dc, self.train_set = dc, train_set
@@ -126,9 +131,14 @@ class Trainer:
         """The 9 inputs of Model.forward (trainer.py:88-96) for the behaviours ``idx`` — news ids stand in for
         title text (the synthetic news 'encoder' is an embedding table)."""
         dc, dev = self.dc, self.dc.news_embedding.device
-        imp = torch.from_numpy(self.train_set.impression[idx]).to(dev)
-        news = torch.from_numpy(self.train_set.samples[idx]).to(dev)               # [B, 1+neg]
-        B, K = news.shape
+        # the step's indices travel as ONE pinned, asynchronous copy: a pageable .to(device) is a blocking copy — the host waits there
+        # until the device has drained the previous step, every step (round 5: 1.5 ms of host time per 7 ms step)
+        samples = self.train_set.samples[idx]                                      # [B, 1+neg]
+        B, K = samples.shape
+        packed = torch.from_numpy(np.concatenate([self.train_set.impression[idx], samples.reshape(-1)]).astype(np.int64, copy=False))
+        if dev.type == "cuda":
+            packed = packed.pin_memory().to(dev, non_blocking=True)
+        imp, news = packed[:B], packed[B:].view(B, K)
         node_ids = dc.news_node_ID.index_select(0, news.flatten()).view(B, K, -1, 1)  # [B,K,N,1]
         hist = dc.history.index_select(0, imp).unsqueeze(2)                        # [B,H,1]
         if dc.title_text is not None:          # a text news encoder (MSA): the titles of the history and of the SAG nodes, as

@@ -34,3 +34,20 @@ for n in (20, 20):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"steps {n}: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, wall {1e3 * (t2 - t0) / n:.3f} ms/step, drain after loop {1e3 * (t2 - t1):.2f} ms")
+
+# which torch ops launch what: one profiled step, ops with their input shapes (where do the element-wise adds come from?)
+if os.environ.get("TRAIN_OPS", "1") != "0":
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    rows = {}
+    for e in prof.events():
+        if e.name.startswith("aten::") or "Backward" in e.name or e.name.startswith("Optimizer"):
+            key = (e.name, str(e.input_shapes)[:90])
+            n, cpu, dev = rows.get(key, (0, 0.0, 0.0))
+            rows[key] = (n + 1, cpu + e.cpu_time_total, dev + e.device_time_total)
+    print(f"{'op':44s} {'shapes':90s} {'n/step':>6s} {'cpu us':>8s} {'dev us':>8s}")
+    for (name, shapes), (n, cpu, dev) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:70]:
+        print(f"{name[:44]:44s} {shapes:90s} {n / 3:6.1f} {cpu / 3:8.1f} {dev / 3:8.1f}")
