@@ -500,6 +500,7 @@ def run_training(W, args, D: Dist, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
+    enqueue_s = time.perf_counter() - t0         # the host's share: when it is close to `elapsed` the step is host-bound in this run
     D.fence()
     elapsed = time.perf_counter() - t0
     roof = None
@@ -537,7 +538,8 @@ def run_training(W, args, D: Dist, steps, warmup):
             ddp["bucket_sizes_bytes"] = str(log.get("bucket_sizes", ""))
         except Exception as exc:          # the logging API is private: report, never fail the run
             ddp = {"error": repr(exc)}
-    return types.SimpleNamespace(elapsed=elapsed, rows_done=steps * 64 * 5, loss=float(loss.item()), roofline=roof, ddp=ddp)
+    return types.SimpleNamespace(elapsed=elapsed, rows_done=steps * 64 * 5, loss=float(loss.item()), roofline=roof, ddp=ddp,
+                                 enqueue_ms_per_step=enqueue_s / steps * 1e3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1048,6 +1050,8 @@ def main():
                                             if args.train_news_encoder == "msa" else "trainable table of news representations"),
                            "parallelism": f"ddp{D.world} (DistributedDataParallel, RCCL all-reduce of the gradients)"},
                 "final_loss": run.loss,
+                # the host's enqueue time per step (no synchronisation inside the loop): close to ms_per_step = this run was host-bound
+                "host_enqueue_ms_per_step": run.enqueue_ms_per_step,
                 # N > 1: the gradient all-reduce as DistributedDataParallel itself times it; N = 1: the step's MFMA launches against the peak
                 "ddp_timers": run.ddp, "backend": D.backend, "ranks_in_process_group": D.world_seen,
                 "roofline": run.roofline(elapsed / args.steps * 1e3) if run.roofline else None}))

@@ -150,11 +150,11 @@ _SIGNATURES = {
     "digat_news_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_fwd_train": (C.c_int, [_f] * 8 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
-    "digat_news_ctx_bwd": (C.c_int, [_f] * 6 + [C.c_float, _f, C.c_size_t] + [_f] * 6 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_news_ctx_bwd": (C.c_int, [_f] * 6 + [C.c_float, _f, C.c_size_t] + [_f] * 6 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_user_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 5),
     "digat_user_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "digat_user_ctx_fwd_train": (C.c_int, [_f] * 13 + [C.c_float, C.c_uint32] + [C.c_int] * 5 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
-    "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 5 + [_f, C.c_size_t, _f]),
+    "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 6 + [_f, C.c_size_t, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),

@@ -414,12 +414,63 @@ class GatFused(Function):
         return dX, None, dW, dbW, da1.view_as(a1), da2.view_as(a2), None
 
 
+class StepSink:
+    """Sums the PARAMETER gradients of the context functions over the depth + 1 calls of one training forward inside the library's
+    weight-gradient launches (``accumulate_params``) instead of one element-wise add per weight and call (36 launches of a step).
+
+    The reference uses one candidate_attention / news_graph_W / user_news_K,Q / featureAffine / userAttention for every layer
+    (graphEncoders.py:177-187), so autograd adds four gradients per weight.  With a sink, the first backward call of a kind
+    allocates the gradient buffers, the later ones add into them in the library, and only the LAST call of the kind returns them to
+    autograd (the others return None for the parameters): AccumulateGrad — and DDP's hooks — fire once per weight with the sum.
+    One sink per forward (``digat_forward_train`` / ``ablation_forward_train`` make it): the count of calls is the forward's own, and
+    every call's output reaches the loss through the c_n / c_u sums.  Should a backward pass end with a kind incomplete (an output
+    that never reached the loss), the pass fails loudly rather than dropping gradients."""
+
+    def __init__(self):
+        self.calls, self.done, self.bufs = {}, {}, {}
+        self._armed = False
+
+    def enter(self, kind):
+        self.calls[kind] = self.calls.get(kind, 0) + 1
+
+    def begin(self, kind, make):
+        """(buffers, accumulate) for this backward call of ``kind``."""
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+        bufs = self.bufs.get(kind)
+        if bufs is None:
+            bufs = self.bufs[kind] = make()
+            return bufs, 0
+        return bufs, 1
+
+    def end(self, kind):
+        """True when this was the kind's last call: the caller hands the buffers to autograd."""
+        self.done[kind] = self.done.get(kind, 0) + 1
+        if self.done[kind] == self.calls.get(kind, 0):
+            del self.bufs[kind]
+            self.done[kind] = 0            # a second backward over a retained graph starts a new sum
+            return True
+        return False
+
+    def _check(self):
+        self._armed = False
+        pending = sorted(self.bufs)
+        if pending:
+            self.bufs.clear(); self.done.clear()
+            raise RuntimeError(f"digat_amd.training.StepSink: the backward pass ended before every {pending} call had run (an output of "
+                               "the graph encoder did not reach the loss): parameter gradients would be incomplete")
+
+
 class NewsCtxFused(Function):
     """compute_news_graph_context (graphEncoders.py:109-114), training mode."""
 
     @staticmethod
-    def forward(ctx, X, mask, Kc, Qc, bQc, Wg, bg, p_gate):
+    def forward(ctx, X, mask, Kc, Qc, bQc, Wg, bg, p_gate, sink=None):
         X = _f(X)
+        ctx.sink = sink
+        if sink is not None:
+            sink.enter("news_ctx")
         B, N, d = X.shape
         dev = X.device
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
@@ -442,20 +493,30 @@ class NewsCtxFused(Function):
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX = torch.empty_like(X)
-        dKc, dQc, dWg = torch.empty_like(Kc), torch.empty_like(Qc), torch.empty_like(Wg)
-        dbQc, dbg = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(2))
+
+        def make():
+            return (torch.empty_like(Kc), torch.empty_like(Qc), torch.empty(d, dtype=torch.float32, device=dev),
+                    torch.empty_like(Wg), torch.empty(d, dtype=torch.float32, device=dev))
+        sink = ctx.sink
+        grads, acc = sink.begin("news_ctx", make) if sink is not None else (make(), 0)
+        dKc, dQc, dbQc, dWg, dbg = grads
         _lib.check(L().digat_news_ctx_bwd(dout.data_ptr(), X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), Wg.data_ptr(),
                                           ctx.p, save.data_ptr(), nsave, dX.data_ptr(), dKc.data_ptr(), dQc.data_ptr(), dbQc.data_ptr(),
-                                          dWg.data_ptr(), dbg.data_ptr(), B, N, d, ws.data_ptr(), nws, S()), "digat_news_ctx_bwd")
-        return dX, None, dKc, dQc, dbQc, dWg, dbg, None
+                                          dWg.data_ptr(), dbg.data_ptr(), B, N, d, acc, ws.data_ptr(), nws, S()), "digat_news_ctx_bwd")
+        if sink is not None and not sink.end("news_ctx"):
+            return dX, None, None, None, None, None, None, None, None
+        return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None
 
 
 class UserCtxFused(Function):
     """compute_user_graph_context (graphEncoders.py:123-134), training mode."""
 
     @staticmethod
-    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic):
+    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic, sink=None):
         Xu, c_n = _f(Xu), _f(c_n)
+        ctx.sink = sink
+        if sink is not None:
+            sink.enter("user_ctx")
         B, U, d = Xu.shape
         dev = Xu.device
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
@@ -482,29 +543,35 @@ class UserCtxFused(Function):
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
-        dKu, dQu, dFa, dKua, dQua = (torch.empty_like(Ku) for _ in range(5))
-        dbQu, dbFa, dbQua = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+
+        def make():
+            return tuple(torch.empty_like(Ku) for _ in range(5)) + tuple(torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+        sink = ctx.sink
+        grads, acc = sink.begin("user_ctx", make) if sink is not None else (make(), 0)
+        dKu, dQu, dFa, dKua, dQua, dbQu, dbFa, dbQua = grads
         _lib.check(L().digat_user_ctx_bwd(dout.data_ptr(), Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(),
                                           Ku.data_ptr(), Qu.data_ptr(), Fa.data_ptr(), Kua.data_ptr(), Qua.data_ptr(), ctx.p,
                                           save.data_ptr(), nsave, dXu.data_ptr(), dc.data_ptr(), dKu.data_ptr(), dQu.data_ptr(),
                                           dbQu.data_ptr(), dFa.data_ptr(), dbFa.data_ptr(), dKua.data_ptr(), dQua.data_ptr(),
-                                          dbQua.data_ptr(), B, U, H, C1, d, ws.data_ptr(), nws, S()), "digat_user_ctx_bwd")
-        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None
+                                          dbQua.data_ptr(), B, U, H, C1, d, acc, ws.data_ptr(), nws, S()), "digat_user_ctx_bwd")
+        if sink is not None and not sink.end("user_ctx"):
+            return (dXu, None, None, dc) + (None,) * 12
+        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
 # the reference's four functions, training mode
 # --------------------------------------------------------------------------------------------------
-def news_graph_context(enc, X, mask_bytes, p, training=True):
+def news_graph_context(enc, X, mask_bytes, p, training=True, sink=None):
     ca, g = enc.candidate_attention, enc.news_graph_W
-    return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0)
+    return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0, sink)
 
 
-def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True):
+def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True, sink=None):
     ua, fa = enc.userAttention, enc.featureAffine
     return UserCtxFused.apply(Xu, cat_mask_bytes, cat_idx, c_n, enc.user_news_K.weight, enc.user_news_Q.weight, enc.user_news_Q.bias,
                               fa.weight, fa.bias, ua.K.weight, ua.Q.weight, ua.Q.bias, enc.max_history_num, enc.category_num,
-                              p if training else 0.0)
+                              p if training else 0.0, sink)
 
 
 def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True):
@@ -572,12 +639,13 @@ def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask,
     """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24)."""
     p, Xn, An, Mn, Xu, Au, cm, ci = _train_inputs(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
                                                   user_graph, user_category_mask, user_category_indices)
-    c_n = news_graph_context(enc, Xn, Mn, p)
-    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p)
+    sink = StepSink() if getattr(enc, "sum_shared_gradients_in_library", True) else None
+    c_n = news_graph_context(enc, Xn, Mn, p, sink=sink)
+    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink)
     for i in range(enc.graph_depth):
         Xn_next = graph_embeddings(enc, "news", i, Xn, An, c_u, p)
         Xu_next = graph_embeddings(enc, "user", i, Xu, Au, c_n, p)
         Xn, Xu = Xn_next, Xu_next
-        c_n = c_n + news_graph_context(enc, Xn, Mn, p)
-        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p)
+        c_n = c_n + news_graph_context(enc, Xn, Mn, p, sink=sink)
+        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink)
     return c_n, c_u

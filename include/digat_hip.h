@@ -423,9 +423,15 @@ size_t digat_news_ctx_train_workspace_bytes(int B, int N, int d);
 int digat_news_ctx_fwd_train(const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* bQc,
                              const float* Wg, const float* bg, float* out, float p_gate, uint32_t seed, int B, int N, int d,
                              void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* accumulate_params != 0: the PARAMETER gradients (dKc, dQc, dbQc, dWg, dbg) are added to what their buffers hold instead of
+ * overwriting it — the context functions' weights are shared by the depth + 1 calls of a step (graphEncoders.py:177-187: one
+ * candidate_attention / news_graph_W for every layer), so a caller can sum a step's gradients in one set of buffers inside the
+ * weight-gradient launches themselves (training.py's StepSink) instead of one element-wise add per weight and call.  dX is always
+ * written. */
 int digat_news_ctx_bwd(const float* dout, const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* Wg,
                        float p_gate, const void* save, size_t save_bytes, float* dX, float* dKc, float* dQc, float* dbQc,
-                       float* dWg, float* dbg, int B, int N, int d, void* workspace, size_t workspace_bytes, void* stream);
+                       float* dWg, float* dbg, int B, int N, int d, int accumulate_params, void* workspace, size_t workspace_bytes,
+                       void* stream);
 /* a4 (+a6, a7) (graphEncoders.py:123-134): topic pooling (scatter_softmax + scatter_sum), featureAffine + relu + residual,
  * drop_{p_topic}, userAttention.  dXu [B,U,d]: history rows get the pooling's gradient, topic rows zero. */
 size_t digat_user_ctx_train_save_bytes(int B, int U, int H, int C1, int d);
@@ -438,6 +444,7 @@ int digat_user_ctx_bwd(const float* dout, const float* Xu, const uint8_t* cat_ma
                        const float* Ku, const float* Qu, const float* Fa, const float* Kua, const float* Qua, float p_topic,
                        const void* save, size_t save_bytes, float* dXu, float* dc_n, float* dKu, float* dQu, float* dbQu,
                        float* dFa, float* dbFa, float* dKua, float* dQua, float* dbQua, int B, int U, int H, int C1, int d,
+                       int accumulate_params /* as digat_news_ctx_bwd: the eight parameter gradients; dXu, dc_n are always written */,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- H2: ranking + metrics of the dev/test driver  (util.py:70-80, evaluate.py:32-89) -------------------

@@ -51,3 +51,5 @@ if os.environ.get("TRAIN_OPS", "1") != "0":
     print(f"{'op':44s} {'shapes':90s} {'n/step':>6s} {'cpu us':>8s} {'dev us':>8s}")
     for (name, shapes), (n, cpu, dev) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:70]:
         print(f"{name[:44]:44s} {shapes:90s} {n / 3:6.1f} {cpu / 3:8.1f} {dev / 3:8.1f}")
+    print()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
