@@ -497,12 +497,39 @@ def run_training(W, args, D: Dist, steps, warmup):
     for _ in range(warmup):
         step()
     D.fence()
+    if os.environ.get("DIGAT_BENCH_CPROFILE"):         # where the host's time goes (diagnostic; changes the timing)
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
+    stamps = [] if os.environ.get("DIGAT_BENCH_STAMPS") else None
+    if stamps is not None:
+        import gc
+        gc_log = []
+        gc.callbacks.append(lambda phase, info: gc_log.append((time.perf_counter(), phase, info.get("generation"))))
+        if os.environ.get("DIGAT_BENCH_STAMPS") == "freeze":
+            gc.collect(); gc.freeze()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
+        if stamps is not None:
+            stamps.append(time.perf_counter())
     enqueue_s = time.perf_counter() - t0         # the host's share: when it is close to `elapsed` the step is host-bound in this run
     D.fence()
     elapsed = time.perf_counter() - t0
+    if stamps:
+        dt = np.diff(np.array([t0] + stamps)) * 1e3
+        print("[bench] host ms per step:", " ".join(f"{v:.1f}" for v in dt), file=sys.stderr)
+        starts = {}
+        for t, phase, gen in gc_log:
+            if phase == "start":
+                starts[gen] = t
+            elif gen in starts and t - starts[gen] > 2e-3:
+                print(f"[bench] gc generation {gen}: {1e3 * (t - starts[gen]):.1f} ms at {1e3 * (starts[gen] - t0):.0f} ms into the timed loop", file=sys.stderr)
     roof = None
     if D.world == 1:
         # untimed: the MFMA launches of three more steps through the library's profiler (forward, input-gradient and
@@ -1063,7 +1090,8 @@ def main():
             raise SystemExit("--mode e2e is a one-GPU run")
         e2e = run_e2e(args, D)
         print(json.dumps({"metric": "MIND-small dev run end to end (title tokens -> rank file), seconds", "value": e2e["seconds"], "unit": "s",
-                          "n_gpus": 1, "steps": e2e["batches"], "warmup": 0, "ms_per_step": e2e["breakdown_s"]["score_all_batches"] / e2e["batches"] * 1e3,
+                          "n_gpus": 1, "steps": e2e["launch_sets"], "warmup": 0,
+                          "ms_per_step": e2e["breakdown_s"]["score_all_batches"] / e2e["launch_sets"] * 1e3,
                           "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": WORKLOADS["mind-small-default"]["label"]}, "e2e": e2e}))
         D.close()

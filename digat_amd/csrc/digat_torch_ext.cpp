@@ -10,7 +10,12 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
+#include <vector>
 
 #include "../../include/digat_hip.h"
 
@@ -132,6 +137,130 @@ void user_row_runs(const at::Tensor& ue, const at::Tensor& Au, const at::Tensor&
           "digat_user_row_runs");
 }
 
+// ---- training: one call per function and direction (digat_*_fwd_train / digat_*_bwd, include/digat_hip.h "training") ---------------
+// The output, `save` and gradient tensors are allocated here and the scratch buffer is cached per (device, stream): a 64 x 5-row
+// step makes 45 of these calls with 20-35 arguments each, and the step was host-bound through their marshalling (round 5).
+
+at::Tensor scratch(const at::Tensor& like, size_t bytes) {       // stream-ordered reuse, as digat_amd/_lib.workspace
+    static std::mutex mu;
+    static std::map<std::pair<int, void*>, at::Tensor> cache;
+    const std::pair<int, void*> key{(int)like.device().index(), stream_of(like)};
+    std::lock_guard<std::mutex> lock(mu);
+    at::Tensor& t = cache[key];
+    if (!t.defined() || (size_t)t.numel() < bytes) t = at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte));
+    return t;
+}
+at::Tensor byte_buffer(const at::Tensor& like, size_t bytes) { return at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte)); }
+float* out_f32(at::Tensor& t) { return t.data_ptr<float>(); }
+
+std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec, const at::Tensor& W,
+                                                   const at::Tensor& bW, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3,
+                                                   const at::Tensor& b3, const at::Tensor& a, double p, int64_t seed) {
+    need(Xd.dim() == 3, "Xd [B,n,d] expected");
+    const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
+    at::Tensor out = at::empty_like(Xd);
+    const size_t nsave = digat_xattn_train_save_bytes(B, n, d), nws = digat_xattn_train_workspace_bytes(B, n, d);
+    at::Tensor save = byte_buffer(Xd, nsave), ws = scratch(Xd, nws);
+    check(digat_xattn_fwd_train(f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"), f32(bW, Xd, "bW"), f32(F1, Xd, "F1"),
+                                f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(b3, Xd, "b3"), f32(a, Xd, "a"), out_f32(out), (float)p, (uint32_t)seed, B, n, d,
+                                save.data_ptr(), nsave, ws.data_ptr(), nws, stream_of(Xd)), "digat_xattn_fwd_train");
+    return {out, save};
+}
+
+// -> dX, dctx, dW3 ([3,d,d]: dW, dF1, dF2 written in place as one product), dbW, dF3, db3, da
+std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out, const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec,
+                                  const at::Tensor& W, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3, const at::Tensor& a, double p,
+                                  const at::Tensor& save) {
+    const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
+    const size_t nsave = digat_xattn_train_save_bytes(B, n, d), nws = digat_xattn_train_workspace_bytes(B, n, d);
+    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    at::Tensor ws = scratch(Xd, nws);
+    at::Tensor dX = at::empty_like(Xd), dc = at::empty_like(cvec), dW3 = at::empty({3, W.size(0), W.size(1)}, W.options()), dF3 = at::empty_like(W);
+    at::Tensor dbW = at::empty({d}, W.options()), db3 = at::empty({d}, W.options()), da = at::empty({d}, W.options());
+    float* w3 = out_f32(dW3);
+    const size_t dd = (size_t)W.size(0) * W.size(1);
+    check(digat_xattn_bwd(f32(dOut, Xd, "dOut"), f32(out, Xd, "out"), f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"),
+                          f32(F1, Xd, "F1"), f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(a, Xd, "a"), (float)p, save.data_ptr(), nsave, out_f32(dX),
+                          out_f32(dc), w3, out_f32(dbW), w3 + dd, w3 + 2 * dd, out_f32(dF3), out_f32(db3), out_f32(da), B, n, d, ws.data_ptr(), nws,
+                          stream_of(Xd)), "digat_xattn_bwd");
+    return {dX, dc, dW3, dbW, dF3, db3, da};
+}
+
+std::tuple<at::Tensor, at::Tensor> news_ctx_fwd_train(const at::Tensor& X, const at::Tensor& mask, const at::Tensor& Kc, const at::Tensor& Qc,
+                                                      const at::Tensor& bQc, const at::Tensor& Wg, const at::Tensor& bg, double p, int64_t seed) {
+    need(X.dim() == 3, "X [B,N,d] expected");
+    const int B = (int)X.size(0), N = (int)X.size(1), d = (int)X.size(2);
+    at::Tensor out = at::empty({B, d}, X.options());
+    const size_t nsave = digat_news_ctx_train_save_bytes(B, N, d), nws = digat_news_ctx_train_workspace_bytes(B, N, d);
+    at::Tensor save = byte_buffer(X, nsave), ws = scratch(X, nws);
+    check(digat_news_ctx_fwd_train(f32(X, X, "X"), bytes(mask, X, "mask"), f32(Kc, X, "Kc"), f32(Qc, X, "Qc"), f32(bQc, X, "bQc"), f32(Wg, X, "Wg"),
+                                   f32(bg, X, "bg"), out_f32(out), (float)p, (uint32_t)seed, B, N, d, save.data_ptr(), nsave, ws.data_ptr(), nws,
+                                   stream_of(X)), "digat_news_ctx_fwd_train");
+    return {out, save};
+}
+
+// grads: dKc, dQc, dbQc, dWg, dbg (the caller's: written, or added to when accumulate); -> dX
+at::Tensor news_ctx_bwd(const at::Tensor& dout, const at::Tensor& X, const at::Tensor& mask, const at::Tensor& Kc, const at::Tensor& Qc,
+                        const at::Tensor& Wg, double p, const at::Tensor& save, std::vector<at::Tensor> grads, bool accumulate) {
+    need(grads.size() == 5, "five parameter-gradient tensors expected");
+    const int B = (int)X.size(0), N = (int)X.size(1), d = (int)X.size(2);
+    const size_t nsave = digat_news_ctx_train_save_bytes(B, N, d), nws = digat_news_ctx_train_workspace_bytes(B, N, d);
+    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    at::Tensor ws = scratch(X, nws), dX = at::empty_like(X);
+    for (auto& g : grads) f32(g, X, "parameter gradient");
+    check(digat_news_ctx_bwd(f32(dout, X, "dout"), f32(X, X, "X"), bytes(mask, X, "mask"), f32(Kc, X, "Kc"), f32(Qc, X, "Qc"), f32(Wg, X, "Wg"), (float)p,
+                             save.data_ptr(), nsave, out_f32(dX), out_f32(grads[0]), out_f32(grads[1]), out_f32(grads[2]), out_f32(grads[3]),
+                             out_f32(grads[4]), B, N, d, accumulate ? 1 : 0, ws.data_ptr(), nws, stream_of(X)), "digat_news_ctx_bwd");
+    return dX;
+}
+
+std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, const at::Tensor& cat_mask, const at::Tensor& cat_idx, const at::Tensor& c_n,
+                                                      const at::Tensor& Ku, const at::Tensor& Qu, const at::Tensor& bQu, const at::Tensor& Fa,
+                                                      const at::Tensor& bFa, const at::Tensor& Kua, const at::Tensor& Qua, const at::Tensor& bQua,
+                                                      int64_t H, int64_t C1, double p, int64_t seed) {
+    need(Xu.dim() == 3, "Xu [B,U,d] expected");
+    const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
+    at::Tensor out = at::empty({B, d}, Xu.options());
+    const size_t nsave = digat_user_ctx_train_save_bytes(B, U, (int)H, (int)C1, d), nws = digat_user_ctx_train_workspace_bytes(B, U, (int)H, (int)C1, d);
+    at::Tensor save = byte_buffer(Xu, nsave), ws = scratch(Xu, nws);
+    check(digat_user_ctx_fwd_train(f32(Xu, Xu, "Xu"), bytes(cat_mask, Xu, "cat_mask"), i64(cat_idx, Xu, "cat_idx"), f32(c_n, Xu, "c_n"), f32(Ku, Xu, "Ku"),
+                                   f32(Qu, Xu, "Qu"), f32(bQu, Xu, "bQu"), f32(Fa, Xu, "Fa"), f32(bFa, Xu, "bFa"), f32(Kua, Xu, "Kua"), f32(Qua, Xu, "Qua"),
+                                   f32(bQua, Xu, "bQua"), out_f32(out), (float)p, (uint32_t)seed, B, U, (int)H, (int)C1, d, save.data_ptr(), nsave,
+                                   ws.data_ptr(), nws, stream_of(Xu)), "digat_user_ctx_fwd_train");
+    return {out, save};
+}
+
+// grads: dKu, dQu, dFa, dKua, dQua, dbQu, dbFa, dbQua (the caller's); -> dXu, dc_n
+std::tuple<at::Tensor, at::Tensor> user_ctx_bwd(const at::Tensor& dout, const at::Tensor& Xu, const at::Tensor& cat_mask, const at::Tensor& cat_idx,
+                                                const at::Tensor& c_n, const at::Tensor& Ku, const at::Tensor& Qu, const at::Tensor& Fa,
+                                                const at::Tensor& Kua, const at::Tensor& Qua, double p, const at::Tensor& save,
+                                                std::vector<at::Tensor> grads, bool accumulate, int64_t H, int64_t C1) {
+    need(grads.size() == 8, "eight parameter-gradient tensors expected");
+    const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
+    const size_t nsave = digat_user_ctx_train_save_bytes(B, U, (int)H, (int)C1, d), nws = digat_user_ctx_train_workspace_bytes(B, U, (int)H, (int)C1, d);
+    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    at::Tensor ws = scratch(Xu, nws), dXu = at::empty_like(Xu), dc = at::empty_like(c_n);
+    for (auto& g : grads) f32(g, Xu, "parameter gradient");
+    check(digat_user_ctx_bwd(f32(dout, Xu, "dout"), f32(Xu, Xu, "Xu"), bytes(cat_mask, Xu, "cat_mask"), i64(cat_idx, Xu, "cat_idx"), f32(c_n, Xu, "c_n"),
+                             f32(Ku, Xu, "Ku"), f32(Qu, Xu, "Qu"), f32(Fa, Xu, "Fa"), f32(Kua, Xu, "Kua"), f32(Qua, Xu, "Qua"), (float)p, save.data_ptr(), nsave,
+                             out_f32(dXu), out_f32(dc), out_f32(grads[0]), out_f32(grads[1]), out_f32(grads[5]), out_f32(grads[2]), out_f32(grads[6]),
+                             out_f32(grads[3]), out_f32(grads[4]), out_f32(grads[7]), B, U, (int)H, (int)C1, d, accumulate ? 1 : 0, ws.data_ptr(), nws,
+                             stream_of(Xu)), "digat_user_ctx_bwd");
+    return {dXu, dc};
+}
+
+std::tuple<at::Tensor, at::Tensor> dropout_fwd(const at::Tensor& x, double p, int64_t seed) {
+    at::Tensor y = at::empty_like(x), mask = at::empty(x.sizes(), x.options().dtype(at::kByte));
+    check(digat_dropout_fwd(f32(x, x, "x"), out_f32(y), static_cast<uint8_t*>(mask.data_ptr()), x.numel(), (float)p, (uint32_t)seed, stream_of(x)),
+          "digat_dropout_fwd");
+    return {y, mask};
+}
+at::Tensor dropout_bwd(const at::Tensor& dy, const at::Tensor& mask, double p) {
+    at::Tensor dx = at::empty_like(dy);
+    check(digat_dropout_bwd(f32(dy, dy, "dy"), bytes(mask, dy, "mask"), out_f32(dx), dy.numel(), (float)p, stream_of(dy)), "digat_dropout_bwd");
+    return dx;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(digat_torch_ext, m) {
@@ -141,4 +270,12 @@ PYBIND11_MODULE(digat_torch_ext, m) {
     m.def("encoder_fwd_grouped", &encoder_fwd_grouped);
     m.def("row_logits", &row_logits);
     m.def("user_row_runs", &user_row_runs);
+    m.def("xattn_fwd_train", &xattn_fwd_train);
+    m.def("xattn_bwd", &xattn_bwd);
+    m.def("news_ctx_fwd_train", &news_ctx_fwd_train);
+    m.def("news_ctx_bwd", &news_ctx_bwd);
+    m.def("user_ctx_fwd_train", &user_ctx_fwd_train);
+    m.def("user_ctx_bwd", &user_ctx_bwd);
+    m.def("dropout_fwd", &dropout_fwd);
+    m.def("dropout_bwd", &dropout_bwd);
 }

@@ -111,6 +111,8 @@ class Trainer:
         self.best_dev_epoch, self.best_dev = 0, None
         self.epoch_not_increase = 0
         self.best_state = None
+        from . import util
+        util.freeze_host_heap()           # the corpus's host-side structures: out of the garbage collector's walks (util.freeze_host_heap)
 
     def lr_decay(self):
         for group in self.optimizer.param_groups:

@@ -144,6 +144,12 @@ class Dropout(Function):
     @staticmethod
     def forward(ctx, x, p):
         x = _f(x)
+        E = _lib.ext()
+        if E is not None:
+            y, mask = E.dropout_fwd(x, float(p), _seed())
+            ctx.save_for_backward(mask)
+            ctx.p = float(p)
+            return y
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         _lib.check(L().digat_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), _seed(), S()),
@@ -156,6 +162,9 @@ class Dropout(Function):
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         dy = _f(dy)
+        E = _lib.ext()
+        if E is not None:
+            return E.dropout_bwd(dy, mask, ctx.p), None
         dx = torch.empty_like(dy)
         _lib.check(L().digat_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, S()),
                    "digat_dropout_bwd")
@@ -344,10 +353,16 @@ class XattnFused(Function):
         Xd, cvec = _f(Xd), _f(cvec)
         B, n, d = Xd.shape
         dev = Xd.device
+        p = float(p_alpha)
+        E = _lib.ext()
+        if E is not None:          # the thin torch extension: tensors in, out / save allocated there (the same C entry)
+            out, save = E.xattn_fwd_train(Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p, _seed() if p > 0 else 0)
+            ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
+            ctx.p, ctx.sizes = p, None
+            return out
         out = torch.empty_like(Xd)
         nsave, nws = L().digat_xattn_train_save_bytes(B, n, d), L().digat_xattn_train_workspace_bytes(B, n, d)
         save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
-        p = float(p_alpha)
         _lib.check(L().digat_xattn_fwd_train(Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
                                              F2.data_ptr(), F3.data_ptr(), b3.data_ptr(), a.data_ptr(), out.data_ptr(), p,
                                              _seed() if p > 0 else 0, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, S()),
@@ -362,6 +377,10 @@ class XattnFused(Function):
         B, n, d = Xd.shape
         dev = Xd.device
         dOut = _f(dOut)
+        E = _lib.ext()
+        if E is not None and ctx.sizes is None:
+            dX, dc, dW3, dbW, dF3, db3, da = E.xattn_bwd(dOut, out, Xd, A, cvec, W, F1, F2, F3, a, ctx.p, save)
+            return dX, None, dc, dW3[0], dbW, dW3[1], dW3[2], dF3, db3, da.view_as(a), None
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX, dc = torch.empty_like(Xd), torch.empty_like(cvec)
@@ -473,6 +492,13 @@ class NewsCtxFused(Function):
             sink.enter("news_ctx")
         B, N, d = X.shape
         dev = X.device
+        E = _lib.ext()
+        if E is not None:
+            p = float(p_gate)
+            out, save = E.news_ctx_fwd_train(X, mask, Kc, Qc, bQc, Wg, bg, p, _seed() if p > 0 else 0)
+            ctx.save_for_backward(X, mask, Kc, Qc, Wg, save)
+            ctx.p, ctx.sizes = p, None
+            return out
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
         nsave, nws = L().digat_news_ctx_train_save_bytes(B, N, d), L().digat_news_ctx_train_workspace_bytes(B, N, d)
         save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
@@ -490,9 +516,6 @@ class NewsCtxFused(Function):
         B, N, d = X.shape
         dev = X.device
         dout = _f(dout)
-        nsave, nws = ctx.sizes
-        ws = _lib.workspace(nws, dev, "train")
-        dX = torch.empty_like(X)
 
         def make():
             return (torch.empty_like(Kc), torch.empty_like(Qc), torch.empty(d, dtype=torch.float32, device=dev),
@@ -500,6 +523,15 @@ class NewsCtxFused(Function):
         sink = ctx.sink
         grads, acc = sink.begin("news_ctx", make) if sink is not None else (make(), 0)
         dKc, dQc, dbQc, dWg, dbg = grads
+        E = _lib.ext()
+        if E is not None and ctx.sizes is None:
+            dX = E.news_ctx_bwd(dout, X, mask, Kc, Qc, Wg, ctx.p, save, list(grads), bool(acc))
+            if sink is not None and not sink.end("news_ctx"):
+                return dX, None, None, None, None, None, None, None, None
+            return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dX = torch.empty_like(X)
         _lib.check(L().digat_news_ctx_bwd(dout.data_ptr(), X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), Wg.data_ptr(),
                                           ctx.p, save.data_ptr(), nsave, dX.data_ptr(), dKc.data_ptr(), dQc.data_ptr(), dbQc.data_ptr(),
                                           dWg.data_ptr(), dbg.data_ptr(), B, N, d, acc, ws.data_ptr(), nws, S()), "digat_news_ctx_bwd")
@@ -519,6 +551,14 @@ class UserCtxFused(Function):
             sink.enter("user_ctx")
         B, U, d = Xu.shape
         dev = Xu.device
+        E = _lib.ext()
+        if E is not None:
+            p = float(p_topic)
+            out, save = E.user_ctx_fwd_train(Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, int(H), int(C1), p,
+                                             _seed() if p > 0 else 0)
+            ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
+            ctx.p, ctx.sizes, ctx.dims = p, None, (H, C1)
+            return out
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
         nsave = L().digat_user_ctx_train_save_bytes(B, U, H, C1, d)
         nws = L().digat_user_ctx_train_workspace_bytes(B, U, H, C1, d)
@@ -540,15 +580,21 @@ class UserCtxFused(Function):
         H, C1 = ctx.dims
         dev = Xu.device
         dout = _f(dout)
-        nsave, nws = ctx.sizes
-        ws = _lib.workspace(nws, dev, "train")
-        dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
 
         def make():
             return tuple(torch.empty_like(Ku) for _ in range(5)) + tuple(torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
         sink = ctx.sink
         grads, acc = sink.begin("user_ctx", make) if sink is not None else (make(), 0)
         dKu, dQu, dFa, dKua, dQua, dbQu, dbFa, dbQua = grads
+        E = _lib.ext()
+        if E is not None and ctx.sizes is None:
+            dXu, dc = E.user_ctx_bwd(dout, Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, ctx.p, save, list(grads), bool(acc), int(H), int(C1))
+            if sink is not None and not sink.end("user_ctx"):
+                return (dXu, None, None, dc) + (None,) * 12
+            return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None
+        nsave, nws = ctx.sizes
+        ws = _lib.workspace(nws, dev, "train")
+        dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
         _lib.check(L().digat_user_ctx_bwd(dout.data_ptr(), Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(),
                                           Ku.data_ptr(), Qu.data_ptr(), Fa.data_ptr(), Kua.data_ptr(), Qua.data_ptr(), ctx.p,
                                           save.data_ptr(), nsave, dXu.data_ptr(), dc.data_ptr(), dKu.data_ptr(), dQu.data_ptr(),

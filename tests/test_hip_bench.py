@@ -188,3 +188,14 @@ def test_bench_train_mode_with_the_msa_news_encoder():
     assert line["unit"] == "rows/s" and line["value"] > 0 and math.isfinite(line["final_loss"])
     assert "MSA" in line["config"]["news_encoder"]
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+
+
+def test_bench_e2e_mode_prints_its_line():
+    """--mode e2e (README: the dev run from title tokens to the rank file) as a stand-alone invocation: one JSON line, seconds."""
+    cmd = [sys.executable, "bench.py", "--mode", "e2e", "--e2e-impressions", "600", "--news", "4096"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "s" and line["higher_is_better"] is False and line["value"] > 0
+    assert line["steps"] == line["e2e"]["launch_sets"] > 0 and line["ms_per_step"] > 0
+    assert line["e2e"]["fp16x3_range_overflow"] is False

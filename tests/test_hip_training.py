@@ -149,6 +149,53 @@ def test_training_gradients_are_reproducible():
         assert torch.equal(grads[0][n], grads[1][n]), n            # ordered reductions: bit-identical
 
 
+def test_both_bindings_and_both_ways_of_summing_shared_gradients_agree():
+    """The training entries through the thin torch extension (the default) and through the ctypes table: the same C calls, the same
+    bits — with dropout live (same seeds from torch's generator).  And the shared context weights' gradients summed inside the
+    library's weight-gradient launches (training.StepSink, the default) against autograd's own sum of four per-call gradients:
+    the same numbers up to the order of three additions."""
+    from digat_amd import _lib
+    assert _lib.ext() is not None, "digat_torch_ext.so has not been built (python -m digat_amd.build)"
+    fx = load_golden("train_step.npz")
+
+    def grads(use_ext, sink, dropout):
+        enc, t, outs, dims = build(fx, dropout=dropout)
+        enc.sum_shared_gradients_in_library = sink
+        torch.manual_seed(1234)
+        _lib.USE_TORCH_EXT = use_ext
+        try:
+            assert (_lib.ext() is not None) == use_ext
+            logits, loss, Xn, ue = run_step(enc, t, dims)
+        finally:
+            _lib.USE_TORCH_EXT = True
+        out = {n: p.grad.clone() for n, p in enc.named_parameters()}
+        out["Xn"], out["ue"], out["loss"] = Xn.grad.clone(), ue.grad.clone(), loss.detach().clone()
+        return out
+    for dropout in (0.0, 0.2):
+        a, b = grads(True, True, dropout), grads(False, True, dropout)
+        for n in a:
+            assert torch.equal(a[n], b[n]), (dropout, n)
+    a, b = grads(True, True, 0.0), grads(True, False, 0.0)
+    for n in a:
+        scale = float(b[n].abs().max())
+        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-6 * max(scale, 1e-12)), (n, float((a[n] - b[n]).abs().max()), scale)
+
+
+def test_an_unused_encoder_output_fails_loudly_instead_of_dropping_gradients():
+    """StepSink hands the shared weights' gradients to autograd with the LAST context call's backward: a loss that never reaches
+    one of the calls would leave the sum incomplete, and the backward pass raises."""
+    fx = load_golden("train_step.npz")
+    enc, t, outs, dims = build(fx, dropout=0.0)
+    B, K, N, H, C, d, L = dims
+
+    def expand(x):
+        return x.unsqueeze(1).expand(B, K, *x.shape[1:]).contiguous().view(B * K, *x.shape[1:])
+    n, u = enc(t["news_graph_embeddings"], t["news_graph"], t["news_graph_mask"], expand(t["user_news_embedding"]), expand(t["user_graph"]),
+               expand(t["user_category_mask"]), expand(t["user_category_indices"]))
+    with pytest.raises(RuntimeError, match="StepSink"):
+        n.sum().backward()                      # c_u's last user-context call never reaches this loss
+
+
 def test_dropout_kernel_statistics_and_train_mode_runs():
     from digat_amd import training
     x = torch.ones(1 << 20, device=DEV)

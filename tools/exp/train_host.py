@@ -26,7 +26,16 @@ def step():
 for _ in range(20):
     step()
 torch.cuda.synchronize()
-for n in (20, 20):
+if os.environ.get("DIGAT_BENCH_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
+for n in (20, 20, 60, 100, 20):
     t0 = time.perf_counter()
     for _ in range(n):
         step()
@@ -53,3 +62,22 @@ if os.environ.get("TRAIN_OPS", "1") != "0":
         print(f"{name[:44]:44s} {shapes:90s} {n / 3:6.1f} {cpu / 3:8.1f} {dev / 3:8.1f}")
     print()
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+
+# per-step host timestamps of a long run: is the slow part periodic (allocator growth, garbage collection, epoch wrap)?
+if os.environ.get("TRAIN_STAMPS"):
+    import gc
+    torch.cuda.synchronize()
+    gc_events = []
+    gc.callbacks.append(lambda phase, info: gc_events.append((time.perf_counter(), phase, info.get("generation"))))
+    stamps = [time.perf_counter()]
+    for _ in range(300):
+        step()
+        stamps.append(time.perf_counter())
+    torch.cuda.synchronize()
+    end = time.perf_counter()
+    dt = np.diff(np.array(stamps)) * 1e3
+    print(f"300 steps: wall {1e3 * (end - stamps[0]) / 300:.3f} ms/step; host per step: median {np.median(dt):.3f}, p90 {np.percentile(dt, 90):.3f}, max {dt.max():.3f} ms")
+    slow = np.flatnonzero(dt > 1.5 * np.median(dt))
+    print("slow steps (index: ms):", ", ".join(f"{i}: {dt[i]:.1f}" for i in slow[:40]))
+    g2 = [(t - stamps[0]) * 1e3 for t, ph, gen in gc_events if ph == "start" and gen == 2]
+    print(f"gc: {sum(1 for e in gc_events if e[1] == 'start')} collections, generation 2 at ms:", [round(x) for x in g2[:20]])
