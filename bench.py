@@ -1098,6 +1098,8 @@ def main():
         return
 
     W = build_workload(name, args, D, args.impressions)
+    from digat_amd import util as _util
+    _util.freeze_host_heap()      # the synthetic corpus's host structures out of the garbage collector's walks (util.compute_scores does the same)
     run = run_inference(W, args, D, args.steps, args.warmup, with_profile=True, gather_scores=D.world > 1)
     range_overflow = bool(W.model.graph_encoder.range_overflowed())
     elapsed = D.reduce([run.elapsed], "max")[0]
