@@ -33,6 +33,8 @@ bash tools/exp/solo_trace.sh $OUT/large --workload mind-large-default --impressi
 bash tools/exp/solo_trace.sh $OUT/default_solo > $OUT/default_solo_kernels.txt 2>&1
 # the other adjacency regime (full histories in 2-4 categories: 16 entries per node), single-stream kernel table
 bash tools/exp/solo_trace.sh $OUT/heavy --workload mind-small-heavy-history --impressions 4096 > $OUT/heavy_solo_kernels.txt 2>&1
+# one 1024-row drop-in pass on one caller stream, launch by launch (queue, start, duration, idle time in front)
+bash tools/exp/dropin_timeline.sh $OUT/dropin > $OUT/dropin_timeline.txt 2>&1
 python3 tools/summarize_profile.py $OUT $OUT/final > $OUT/summary.txt 2>&1
 # the matrix-core ceiling of the projection GEMM's tiling (operands resident: no DMA, no split) and the training step's kernel table
 [ -x tools/exp/mfma_ceiling ] && ./tools/exp/mfma_ceiling > $OUT/mfma_ceiling.txt 2>&1

@@ -17,6 +17,7 @@ cp $S/skinny_pmc.txt ${P}_skinny_split_pmc.txt
 cp $S/topic_pmc.txt ${P}_topic_pmc.txt
 cp $S/timed_region_kernels.txt ${P}_timed_region_kernels.txt
 for w in default stress large heavy; do cp $S/${w}_solo_kernels.txt ${P}_${w}_solo_kernels.txt; done
+[ -f $S/dropin_timeline.txt ] && cp $S/dropin_timeline.txt ${P}_dropin_timeline.txt
 [ -f $S/mfma_ceiling.txt ] && cp $S/mfma_ceiling.txt ${P}_mfma_ceiling.txt
 [ -f $S/train_step_kernels.txt ] && cp $S/train_step_kernels.txt ${P}_train_step_kernels.txt
 ls -la ${P}_*
