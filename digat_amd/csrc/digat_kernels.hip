@@ -243,7 +243,8 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       const void* wsplit = nullptr, const int* rowidx = nullptr, const int* nrows_dev = nullptr,
                       const uint8_t* live = nullptr, int sparse_mode = DIGAT_XATTN_DENSE, const int* sparse_flag = nullptr,
                       int pq_x3 = 0, const PlanBuffers* plan = nullptr, int plan_slot = 0, int pq_mode = 0, int centre_limit = 0,
-                      int gemm_format = 0, unsigned* range_flag = nullptr, const TwinLists* tw = nullptr, const SplitIO* sio = nullptr) {
+                      int gemm_format = 0, unsigned* range_flag = nullptr, const TwinLists* tw = nullptr, const SplitIO* sio = nullptr,
+                      int prof_part = 0) {
     const size_t nd = (size_t)B * n * d;
     float* h = (float*)workspace;
     float* P = h + nd;
@@ -279,6 +280,7 @@ static int xattn_core(const float* X, const uint8_t* A, const float* r_given,
                       sparse_mode == DIGAT_XATTN_AUTO ? sparse_flag : nullptr, B, n, d / 4, 0, nullptr, nullptr,
                       listed && live ? rowidx : nullptr, listed && live ? nrows_dev : nullptr, 0, nullptr, pq8 ? 2 : (pq16 ? 1 : 0), plan ? 0 : centre_limit};
         sg.ld8 = pq8 ? ld8 : 0;
+        sg.prof_part = prof_part;
         if (tw && listed && live && !plan) { sg.twin = tw->word; sg.twlist = tw->list; sg.twcount = tw->count; }
         if (sio && sio->out && listed && live && !plan && sparse_mode == DIGAT_XATTN_SPARSE) { sg.xsplit = sio->out; sg.xsplit_range = sio->range; }
         // with a plan of the batch (encoder entry points): the LDS-staged kernel, each needed row read once (digat_staged.inc)
@@ -578,6 +580,10 @@ static size_t live_group_bytes(int B, int U, int C1) {
     const size_t Gm = (size_t)B / 4 + 1;
     return 2 * align_up(Gm * U, 256) + align_up(Gm * U * 4, 256) + align_up(Gm * C1, 256) + 5 * align_up(Gm * 4, 256);
 }
+// live nodes of the news graphs (news_live_flags_kernel): cnt [B], off [B + 1], list [B N] (int) and flags [B N] (bytes)
+static size_t news_live_bytes(int B, int N) {
+    return (align_up((size_t)B, 64) + align_up((size_t)B + 1, 64) + align_up((size_t)B * N, 64)) * 4 + align_up((size_t)B * N, 256);
+}
 struct SideStream { hipStream_t s; hipEvent_t fork, join, early; int ok; };
 // Nothing below is mutable: live-row lists and the side stream are chosen PER CALL through digat_params.flags
 // (DIGAT_PARAMS_NO_LIVE_ROWS, DIGAT_PARAMS_SIDE_STREAM_OFF / _ON), so two host threads with different settings cannot flip each
@@ -636,7 +642,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                               const float* Xg0, const float* news_hpq0, const float* hist_hpq0, const float* topic_hpq0, void* plan_ws,
                               void* chunk_ws, unsigned char* xsplit_ws, const uint8_t* Au_g, const uint8_t* cm_g, const int64_t* ci_g, const float* ctxq0,
                               const int64_t* news_index, int64_t news_rows, const float* c_n_src, void* live_g_ws = nullptr,
-                              const uint8_t* run_leader = nullptr, const uint8_t* run_lead = nullptr) {
+                              const uint8_t* run_leader = nullptr, const uint8_t* run_lead = nullptr, void* news_live_ws = nullptr) {
     // SHARED-USER RUNS (digat_encoder_fwd_shared; round 5): the user tensors are given per ROW, as the reference's driver hands them
     // over (util.py:57-67), and consecutive rows with identical users were found on the device: row_group[b] = the ROW that leads
     // row b's run, run_leader[b] = 1 for those rows, run_lead[b] = rows of the layer-0 chunk row b leads.  Layer 0's group-level
@@ -989,6 +995,11 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     if (rc) return rc;
     const float* xn_cur = Xn_in;
     int un = 0, nn = 0;
+    // Larger news graphs (N > 16) on the sparse kernel: their padding slots are dead nodes — neither projected nor scored nor written
+    // in any layer (news_live_flags_kernel); the context pooling masks them and skips zero weights, nobody else reads them.
+    const bool news_lists = L > 0 && news_live_ws && !news_early && (p->flags & DIGAT_NEWS_XATTN_SPARSE) && N > 16 && d / 4 <= 256 &&
+                            !(p->flags & DIGAT_PARAMS_NO_LIVE_ROWS) && LAB_ENV("DIGAT_NEWS_LIVE", 1) != 0;
+    const int* news_rowidx = nullptr; const int* news_nrows = nullptr; const uint8_t* news_flags = nullptr;
     for (int i = 0; i < L; ++i) {
         const digat_layer_params& ln = p->news[i];
         const digat_layer_params& lu = p->user[i];
@@ -1087,6 +1098,22 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             rc = launch_gemm(g3, sn);
         }
         if (rc) return rc;
+        if (i == 0 && news_lists) {            // the live nodes of the news graphs, once per pass (the graphs do not change with the layers)
+            int* cnt_n = (int*)news_live_ws;
+            int* off_n = cnt_n + align_up((size_t)B, 64);
+            int* idx_n = off_n + align_up((size_t)B + 1, 64);
+            uint8_t* flags_n = (uint8_t*)(idx_n + align_up((size_t)B * N, 64));
+            ProfScope prof(DIGAT_KERNEL_GLUE, (double)B * ((double)N * N + 6.0 * N), sn);
+            hipLaunchKernelGGL(news_live_flags_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * ((N * N + 15) & ~15), sn, An, Mn, B, N, flags_n, cnt_n);
+            DIGAT_CHECK_LAUNCH();
+            ScanPair sp{{cnt_n}, {off_n}, {nullptr}};
+            ListPair lp{{flags_n}, {off_n}, {N, N, N, N, N, N}, {idx_n}, {nullptr}};
+            hipLaunchKernelGGL(exclusive_scan2_kernel, dim3(1), dim3(1024), 0, sn, sp, B);
+            DIGAT_CHECK_LAUNCH();
+            hipLaunchKernelGGL(live_list2_kernel, dim3((B + 3) / 4, 1), dim3(256), 0, sn, lp, B);
+            DIGAT_CHECK_LAUNCH();
+            news_rowidx = idx_n; news_nrows = off_n + B; news_flags = flags_n;
+        }
         if (news_early) {        // projections already done (news_project below): K3 joins in the score kernel
             const size_t ndn = (size_t)B * N * d;
             const float* hn = (i == 0 && news_hpq0) ? news_hpq0 : (const float*)xws_news;
@@ -1105,17 +1132,19 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
             int* idx32 = (int*)((char*)chunk_ws + l0_chunk_bytes(B, U) - align_up((size_t)B * 4, 256));
             hipLaunchKernelGGL(index_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, sn, news_index, idx32, B);
             DIGAT_CHECK_LAUNCH();
-            SparseArgs sgn{news_hpq0 + plane, news_hpq0 + 2 * plane, news_hpq0, xn_cur, ln.a, An, Xn[nn], r_news, idx32, nullptr,
-                           nullptr, B, N, d / 4, 1, nullptr, nullptr, nullptr, nullptr, B, nullptr, 0, 0};      // G (profiling: distinct rows behind the index): at most B candidates
+            SparseArgs sgn{news_hpq0 + plane, news_hpq0 + 2 * plane, news_hpq0, xn_cur, ln.a, An, Xn[nn], r_news, idx32, news_flags,
+                           nullptr, B, N, d / 4, 1, nullptr, nullptr, news_rowidx, news_nrows, B, nullptr, 0, 0};      // G (profiling: distinct rows behind the index): at most B candidates
+            if (news_rowidx) sgn.prof_part = XPART_NEWS + 1;
             rc = launch_sparse(sgn, sn);
         } else {
             // larger news graphs (N = 26 / 65: the breadth-first SAG, a few entries per node) take the sparse kernel when the
             // caller says so (flags bit 3); there is no device-side decision for this graph
             rc = xattn_core(xn_cur, An, r_news, ln.W, ln.bW, ln.F1, ln.F2, ln.a, Xn[nn], nullptr, B, N, d, xws_news, sn, ln.wsplit,
-                            nullptr, nullptr, nullptr, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
+                            news_rowidx, news_nrows, news_flags, (p->flags & DIGAT_NEWS_XATTN_SPARSE) ? DIGAT_XATTN_SPARSE : DIGAT_XATTN_DENSE,
                             nullptr, pq_x3, nullptr, 0,
                             // the news graph's P' always carries K3 from the GEMM epilogue: bf16 storage applies at every layer
-                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) | ((p->flags & DIGAT_PQ_FP8) ? 4 : 0), 0, fmt, rflag);
+                            ((p->flags & DIGAT_PQ_BF16) ? 1 : 0) | ((p->flags & DIGAT_PQ_X1) ? 2 : 0) | ((p->flags & DIGAT_PQ_FP8) ? 4 : 0), 0, fmt, rflag,
+                            nullptr, nullptr, news_rowidx ? XPART_NEWS + 1 : 0);
         }
         if (rc) return rc;
         xn_cur = Xn[nn]; nn ^= 1; un ^= 1;
@@ -1173,6 +1202,7 @@ size_t digat_encoder_workspace_bytes(int B, int N, int H, int C, int d, int dept
     // + adjacency entries per row and the sparse / dense decision (int)
     tot += align_up((4 * align_up((size_t)B, 64) + 2 * align_up((size_t)B + 1, 64) + align_up((size_t)B * U, 64)
                      + align_up((size_t)B * (C + 1), 64) + 64) * 4 + align_up((size_t)B * U, 256) + align_up((size_t)B * (C + 1), 256), 256);
+    tot += news_live_bytes(B, N);                         // larger news graphs on the sparse kernel: live-node flags, counts, offsets, list
     tot += xsplit_bytes(B, U, d);                         // LAB builds: the user nodes as split fp16 pairs between two layers (SplitIO)
     tot += l0_chunk_bytes(B, U);                          // layer 0 of grouped rows: group starts + rows led by each row (xattn_sparse_l0_kernel)
     tot += plan_bytes(B, U);                             // the staged Eq. 8 kernel's plan of the batch (digat_staged.inc)
@@ -1230,6 +1260,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
     void* plan_ws = (char*)workspace + digat_encoder_workspace_bytes(B, N, H, C, d, L) - plan_bytes(B, U);
     void* chunk_ws = (char*)plan_ws - l0_chunk_bytes(B, U);
     unsigned char* xsplit_ws = xsplit_bytes(B, U, d) ? (unsigned char*)chunk_ws - xsplit_bytes(B, U, d) : nullptr;
+    void* news_live_ws = (char*)chunk_ws - xsplit_bytes(B, U, d) - news_live_bytes(B, N);
 
     int rc;
     const bool folded = p->cand_fold_W && p->user_news_fold_W && p->userAtt_fold_W;
@@ -1271,7 +1302,7 @@ static int encoder_fwd_impl(const digat_params* p, const float* Xn_in, const uin
         return encoder_fwd_folded(p, Xn_in, An, Mn, Au, cat_mask, cat_idx, out_news, out_user, B, N, H, Xu, Xn, xws,
                                   xws_news, cws, kq_t, kq_u, r_user2, r_news, live_ws, st, row_group, G, ue, Xg0, news_hpq0, hist_hpq0, topic_hpq0, plan_ws, chunk_ws, xsplit_ws, Au_g, cm_g, ci_g,
                                   c_n0 ? ctxq0 : nullptr, news_index, news_rows, c_n0_in_place ? c_n0 : out_news, live_g_ws,
-                                  run_leader, run_lead);
+                                  run_leader, run_lead, news_live_ws);
     // c_u (:192)
     rc = digat_user_ctx_fwd(Xu[0], cat_mask, cat_idx, out_news, p->user_news_K, p->user_news_Q, p->user_news_bQ,
                             p->featureAffine_W, p->featureAffine_b, p->userAtt_K, p->userAtt_Q, p->userAtt_bQ,

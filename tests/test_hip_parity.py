@@ -1320,3 +1320,50 @@ def test_gather_tables_equals_index_select():
     assert torch.equal(out_graph, graph[uniq])
     assert torch.equal(out_odd, odd[uniq])
     assert torch.equal(out_cand, emb[cand])
+
+
+@pytest.mark.parametrize("neighbors", [5, 8], ids=["N26", "N65"])
+def test_dead_news_nodes_are_skipped_and_never_read(neighbors):
+    """Round 5: on the sparse kernel the padding slots of a larger news graph are dead nodes — not projected, scored or written in
+    any layer (news_live_flags_kernel).  Against the oracle on graphs that try to break the liveness rule: a padding slot that a
+    real node DOES point at (and which itself has no entry: uniform over every node), a real node without any entry, a news
+    without neighbours (the pooling is uniform over every node), next to ordinary SAG graphs; the scratch is poisoned with NaN
+    patterns first (0 x NaN: a dead row that is read would show), and skipping nothing (live_rows off) gives the same bits."""
+    from digat_amd import _lib, synthetic
+    N = synthetic.news_graph_size(neighbors, 2)
+    B, H, C, d, L = 128, 50, 17, 400, 3
+    state = synthetic.make_state_dict(d, C, L, seed=161, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=162, isolated_news_rows=(3,))
+    A, M = batch["news_graph"], batch["news_graph_mask"]
+    assert M.mean() < 0.95 and (~M[:, 1:]).any(), "the generator no longer pads news graphs: this test needs padding slots"
+    pad = [(b, int(np.flatnonzero(~M[b, 1:])[0]) + 1) for b in range(B) if (~M[b, 1:]).any()]
+    (b1, j1), (b2, j2) = pad[0], pad[1]
+    real1 = int(np.flatnonzero(M[b1])[0])
+    A[b1, real1, j1] = True            # a real node reads a padding slot ...
+    A[b1, j1, :] = False               # ... which has no entry of its own: uniform over all N nodes
+    real2 = int(np.flatnonzero(M[b2])[-1])
+    A[b2, real2, :] = False            # a real node without any entry
+    with torch.no_grad():
+        wn, wu = O.encoder_forward(O.as_params(state), L, *O.batch_tensors(batch))
+    enc = make_encoder(state, N, H, C, d, L)
+    enc.news_xattn_mode = "sparse"
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    args = [to_dev(batch)[k] for k in keys]
+
+    def poison():
+        torch.cuda.synchronize()
+        for buf in _lib._workspaces.values():
+            buf.fill_(255)
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        enc(*args)                                                     # sizes the workspaces
+        poison()
+        gn, gu = enc(*args)
+        with enc.launch_options(live_rows=False):
+            poison()
+            fn, fu = enc(*args)
+    assert torch.isfinite(gn).all() and torch.isfinite(gu).all()
+    close(gn, wn, f"N={N}: news ctx", rtol=2e-5, atol=2e-5)
+    close(gu, wu, f"N={N}: user ctx", rtol=2e-5, atol=2e-5)
+    assert torch.equal(gn, fn) and torch.equal(gu, fu)
