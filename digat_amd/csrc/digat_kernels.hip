@@ -874,6 +874,14 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     // the news nodes, so they are issued on the side stream a phase early — layer 0's under the initial user context,
     // layer i+1's under the pooling of user context i — instead of waiting for c_u.
     const bool news_early = L > 0 && N <= 16 && d / 4 <= 256;       // same arithmetic with and without the side stream
+    // The padding slots of a news graph are dead nodes — neither projected nor (on the sparse kernel) scored or written in any layer
+    // (news_live_flags_kernel); the context pooling masks them and skips zero weights, nobody else reads them.  Larger graphs
+    // (N > 16, sparse kernel): projection and Eq. 8 run on the live list.  Small graphs: the projections of layers >= 1 do; the
+    // one-workgroup-per-graph Eq. 8 kernel still computes every centre (a live centre visits its adjacency entries only: live nodes).
+    const bool news_lists_on = L > 0 && news_live_ws && d / 4 <= 256 && !(p->flags & DIGAT_PARAMS_NO_LIVE_ROWS) && LAB_ENV("DIGAT_NEWS_LIVE", 1) != 0;
+    const bool news_lists = news_lists_on && ((!news_early && (p->flags & DIGAT_NEWS_XATTN_SPARSE) && N > 16) || (news_early && L > 1 && B >= 2048));
+    // (small graphs below 2 048 rows: the three list launches sit on the news chain's critical path and cost what two smaller projections save)
+    const int* news_rowidx = nullptr; const int* news_nrows = nullptr; const uint8_t* news_flags = nullptr;
     auto news_project = [&](int layer, const float* Xn_cur, hipStream_t sq) -> int {
         const digat_layer_params& ln = p->news[layer];
         const size_t ndn = (size_t)B * N * d;
@@ -887,6 +895,7 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
                                        // (digat_news_project0 makes the same launch per news, once)
         gp.wsplit = (const unsigned short*)ln.wsplit;
         gp.format = fmt; gp.range_flag = rflag;
+        if (news_rowidx && gemm_is_bf16x6(gp)) { gp.rowidx = news_rowidx; gp.nrows_dev = news_nrows; }      // live nodes only (layers >= 1)
         return launch_gemm(gp, sq, DIGAT_KERNEL_PROJ);
     };
     // layer 0 of grouped rows: every row of a group has the same user nodes, so the G groups are projected once
@@ -995,11 +1004,6 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     if (rc) return rc;
     const float* xn_cur = Xn_in;
     int un = 0, nn = 0;
-    // Larger news graphs (N > 16) on the sparse kernel: their padding slots are dead nodes — neither projected nor scored nor written
-    // in any layer (news_live_flags_kernel); the context pooling masks them and skips zero weights, nobody else reads them.
-    const bool news_lists = L > 0 && news_live_ws && !news_early && (p->flags & DIGAT_NEWS_XATTN_SPARSE) && N > 16 && d / 4 <= 256 &&
-                            !(p->flags & DIGAT_PARAMS_NO_LIVE_ROWS) && LAB_ENV("DIGAT_NEWS_LIVE", 1) != 0;
-    const int* news_rowidx = nullptr; const int* news_nrows = nullptr; const uint8_t* news_flags = nullptr;
     for (int i = 0; i < L; ++i) {
         const digat_layer_params& ln = p->news[i];
         const digat_layer_params& lu = p->user[i];
