@@ -601,9 +601,13 @@ def rooflines(W, run, args):
                 continue
             if doc.get("rows_per_step", 1024) != args.batch:      # per-launch bytes belong to the launch size they were counted at
                 continue
-            for name, v in table.items():
-                if symbols.get(kind, "\0") in name:
-                    return {"bytes_per_launch": v["hbm_bytes_mean"], "kernel": name, "source": os.path.relpath(path, REPO)}
+            # every instantiation of the kind's kernel (the projection GEMM launches as <3,true,2,...> on big row counts and
+            # <3,true,1,...> on the small news-side ones): the launch-weighted mean, like the kind's own average launch time
+            hits = [(name, v) for name, v in table.items() if symbols.get(kind, "\0") in name]
+            if hits:
+                n = sum(v["launches"] for _, v in hits)
+                return {"bytes_per_launch": sum(v["hbm_bytes_mean"] * v["launches"] for _, v in hits) / max(n, 1),
+                        "kernel": max(hits, key=lambda h: h[1]["hbm_bytes_mean"] * h[1]["launches"])[0], "source": os.path.relpath(path, REPO)}
         return None
 
     def roof_of(kind, v):
