@@ -143,10 +143,11 @@ void user_row_runs(const at::Tensor& ue, const at::Tensor& Au, const at::Tensor&
 
 at::Tensor scratch(const at::Tensor& like, size_t bytes) {       // stream-ordered reuse, as digat_amd/_lib.workspace
     static std::mutex mu;
-    static std::map<std::pair<int, void*>, at::Tensor> cache;
+    // never destroyed: a tensor released by a static destructor at interpreter exit would reach the allocator after it is gone
+    static auto* cache = new std::map<std::pair<int, void*>, at::Tensor>();
     const std::pair<int, void*> key{(int)like.device().index(), stream_of(like)};
     std::lock_guard<std::mutex> lock(mu);
-    at::Tensor& t = cache[key];
+    at::Tensor& t = (*cache)[key];
     if (!t.defined() || (size_t)t.numel() < bytes) t = at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte));
     return t;
 }
