@@ -144,6 +144,17 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_a
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
+// The same copy with the source as (wave-uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): no 64-bit vector add per
+// piece, and M0 is written but neither saved nor restored (round 5: the GEMM's main loop is bound by instruction ISSUE — 1.5
+// non-MFMA instructions per MFMA — and a third of those were this helper's M0 save / restore and its callers' address adds).
+// Only for kernels in which nothing else depends on M0 (gfx9 LDS instructions do not; the ISA of every user is checked for it).
+__device__ __forceinline__ void lds_dma16_s(const void* sbase_any, unsigned voff, unsigned lds_byte_addr) {
+    // the base IS wave-uniform; where the compiler cannot prove it (a row count loaded from memory) it is made so explicitly
+    const unsigned long long bits = (unsigned long long)(uintptr_t)sbase_any;
+    const void* sbase = (const void*)(uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) |
+                                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)bits));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {        // s_waitcnt vmcnt(N) with a compile-time N (0 .. 63)
     // gfx9 encoding of the s_waitcnt immediate: vmcnt low bits [3:0], expcnt [6:4] = 7, lgkmcnt [11:8] = 15, vmcnt high bits [15:14]
