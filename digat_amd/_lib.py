@@ -169,6 +169,7 @@ _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 XATTN_PARTS = ("twin", "l0", "news", "other")      # digat_profile_xattn_parts: the Eq. 8 launches by kernel
 EXPORTED = tuple(_SIGNATURES)
+ABI_VERSION = 2          # include/digat_hip.h: DIGAT_ABI_VERSION the signature table above was written for
 
 
 def lib() -> C.CDLL:
@@ -180,6 +181,13 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -m digat_amd.build` or __graft_entry__.build()). There is no CPU fallback.")
         handle = C.CDLL(LIB_PATH)
+        handle.digat_version.restype, handle.digat_version.argtypes = C.c_int, []
+        got = handle.digat_version()
+        if got != ABI_VERSION:
+            # an older or newer build (DIGAT_HIP_LIB, a stale .so): its entry points may take other argument lists — refuse it rather
+            # than call through shifted arguments
+            raise DigatHipError(f"{LIB_PATH} reports ABI version {got}, this loader's signature table is for version {ABI_VERSION}: "
+                                "rebuild it from this tree (python -m digat_amd.build)")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args

@@ -9,6 +9,7 @@
 // otherwise: both roads end in the same shared object, there is no CPU path on either.
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
 
 #include <algorithm>
 #include <map>
@@ -52,6 +53,13 @@ const int32_t* i32(const at::Tensor& t, const at::Tensor& like, const char* name
 void* stream_of(const at::Tensor& t) {
     TORCH_CHECK(t.is_cuda(), "digat_torch_ext: GPU tensors only (there is no CPU path)");
     return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+// shapes the raw-pointer kernels assume (round 6, ADVICE r05: a wrong-shaped tensor used to reach them unchecked)
+void shape(const at::Tensor& t, std::initializer_list<int64_t> want, const char* name) {
+    bool ok = t.dim() == (int64_t)want.size();
+    int64_t k = 0;
+    if (ok) for (int64_t w : want) { ok = ok && t.size(k) == w; ++k; }
+    TORCH_CHECK(ok, "digat_torch_ext: ", name, " has shape ", t.sizes(), ", expected ", at::IntArrayRef(want.begin(), want.size()));
 }
 void check(int rc, const char* what) {
     TORCH_CHECK(rc == DIGAT_OK, "digat_torch_ext: ", what, " failed: [", rc, "] ", digat_error_string(rc));
@@ -159,6 +167,9 @@ std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const a
                                                    const at::Tensor& b3, const at::Tensor& a, double p, int64_t seed) {
     need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
+    const c10::DeviceGuard guard(Xd.device());          // allocations and the launch on the input's device, whatever the current one is
+    shape(A, {B, n, n}, "A"); shape(cvec, {B, d}, "ctx"); shape(W, {d, d}, "W"); shape(F1, {d, d}, "F1"); shape(F2, {d, d}, "F2"); shape(F3, {d, d}, "F3");
+    shape(bW, {d}, "bW"); shape(b3, {d}, "b3"); need(a.numel() == d, "a [1,d] expected");
     at::Tensor out = at::empty_like(Xd);
     const size_t nsave = digat_xattn_train_save_bytes(B, n, d), nws = digat_xattn_train_workspace_bytes(B, n, d);
     at::Tensor save = byte_buffer(Xd, nsave), ws = scratch(Xd, nws);
@@ -172,9 +183,14 @@ std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const a
 std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out, const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec,
                                   const at::Tensor& W, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3, const at::Tensor& a, double p,
                                   const at::Tensor& save) {
+    need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
+    const c10::DeviceGuard guard(Xd.device());
+    shape(dOut, {B, n, d}, "dOut"); shape(out, {B, n, d}, "out"); shape(A, {B, n, n}, "A"); shape(cvec, {B, d}, "ctx");
+    shape(W, {d, d}, "W"); shape(F1, {d, d}, "F1"); shape(F2, {d, d}, "F2"); shape(F3, {d, d}, "F3"); need(a.numel() == d, "a [1,d] expected");
     const size_t nsave = digat_xattn_train_save_bytes(B, n, d), nws = digat_xattn_train_workspace_bytes(B, n, d);
-    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    need(save.is_cuda() && save.device() == Xd.device() && save.scalar_type() == at::kByte && save.is_contiguous() && (size_t)save.numel() >= nsave,
+         "save: the uint8 buffer the forward call returned (same device, same shapes)");
     at::Tensor ws = scratch(Xd, nws);
     at::Tensor dX = at::empty_like(Xd), dc = at::empty_like(cvec), dW3 = at::empty({3, W.size(0), W.size(1)}, W.options()), dF3 = at::empty_like(W);
     at::Tensor dbW = at::empty({d}, W.options()), db3 = at::empty({d}, W.options()), da = at::empty({d}, W.options());
@@ -191,6 +207,8 @@ std::tuple<at::Tensor, at::Tensor> news_ctx_fwd_train(const at::Tensor& X, const
                                                       const at::Tensor& bQc, const at::Tensor& Wg, const at::Tensor& bg, double p, int64_t seed) {
     need(X.dim() == 3, "X [B,N,d] expected");
     const int B = (int)X.size(0), N = (int)X.size(1), d = (int)X.size(2);
+    const c10::DeviceGuard guard(X.device());
+    shape(mask, {B, N}, "mask"); shape(Kc, {d, d}, "Kc"); shape(Qc, {d, d}, "Qc"); shape(bQc, {d}, "bQc"); shape(Wg, {d, 2 * d}, "Wg"); shape(bg, {d}, "bg");
     at::Tensor out = at::empty({B, d}, X.options());
     const size_t nsave = digat_news_ctx_train_save_bytes(B, N, d), nws = digat_news_ctx_train_workspace_bytes(B, N, d);
     at::Tensor save = byte_buffer(X, nsave), ws = scratch(X, nws);
@@ -204,9 +222,14 @@ std::tuple<at::Tensor, at::Tensor> news_ctx_fwd_train(const at::Tensor& X, const
 at::Tensor news_ctx_bwd(const at::Tensor& dout, const at::Tensor& X, const at::Tensor& mask, const at::Tensor& Kc, const at::Tensor& Qc,
                         const at::Tensor& Wg, double p, const at::Tensor& save, std::vector<at::Tensor> grads, bool accumulate) {
     need(grads.size() == 5, "five parameter-gradient tensors expected");
+    need(X.dim() == 3, "X [B,N,d] expected");
     const int B = (int)X.size(0), N = (int)X.size(1), d = (int)X.size(2);
+    const c10::DeviceGuard guard(X.device());
+    shape(dout, {B, d}, "dout"); shape(mask, {B, N}, "mask"); shape(Kc, {d, d}, "Kc"); shape(Qc, {d, d}, "Qc"); shape(Wg, {d, 2 * d}, "Wg");
+    shape(grads[0], {d, d}, "dKc"); shape(grads[1], {d, d}, "dQc"); shape(grads[2], {d}, "dbQc"); shape(grads[3], {d, 2 * d}, "dWg"); shape(grads[4], {d}, "dbg");
     const size_t nsave = digat_news_ctx_train_save_bytes(B, N, d), nws = digat_news_ctx_train_workspace_bytes(B, N, d);
-    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    need(save.is_cuda() && save.device() == X.device() && save.scalar_type() == at::kByte && save.is_contiguous() && (size_t)save.numel() >= nsave,
+         "save: the uint8 buffer the forward call returned (same device, same shapes)");
     at::Tensor ws = scratch(X, nws), dX = at::empty_like(X);
     for (auto& g : grads) f32(g, X, "parameter gradient");
     check(digat_news_ctx_bwd(f32(dout, X, "dout"), f32(X, X, "X"), bytes(mask, X, "mask"), f32(Kc, X, "Kc"), f32(Qc, X, "Qc"), f32(Wg, X, "Wg"), (float)p,
@@ -221,6 +244,11 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, cons
                                                       int64_t H, int64_t C1, double p, int64_t seed) {
     need(Xu.dim() == 3, "Xu [B,U,d] expected");
     const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
+    const c10::DeviceGuard guard(Xu.device());
+    need(H >= 0 && H <= U && C1 >= 1, "H history rows of the U nodes, C1 = category_num + 1 buckets");
+    shape(cat_mask, {B, C1}, "cat_mask"); shape(cat_idx, {B, H}, "cat_idx"); shape(c_n, {B, d}, "c_n");
+    shape(Ku, {d, d}, "Ku"); shape(Qu, {d, d}, "Qu"); shape(bQu, {d}, "bQu"); shape(Fa, {d, d}, "Fa"); shape(bFa, {d}, "bFa");
+    shape(Kua, {d, d}, "Kua"); shape(Qua, {d, d}, "Qua"); shape(bQua, {d}, "bQua");
     at::Tensor out = at::empty({B, d}, Xu.options());
     const size_t nsave = digat_user_ctx_train_save_bytes(B, U, (int)H, (int)C1, d), nws = digat_user_ctx_train_workspace_bytes(B, U, (int)H, (int)C1, d);
     at::Tensor save = byte_buffer(Xu, nsave), ws = scratch(Xu, nws);
@@ -237,9 +265,17 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_bwd(const at::Tensor& dout, const at
                                                 const at::Tensor& Kua, const at::Tensor& Qua, double p, const at::Tensor& save,
                                                 std::vector<at::Tensor> grads, bool accumulate, int64_t H, int64_t C1) {
     need(grads.size() == 8, "eight parameter-gradient tensors expected");
+    need(Xu.dim() == 3, "Xu [B,U,d] expected");
     const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
+    const c10::DeviceGuard guard(Xu.device());
+    need(H >= 0 && H <= U && C1 >= 1, "H history rows of the U nodes, C1 = category_num + 1 buckets");
+    shape(dout, {B, d}, "dout"); shape(cat_mask, {B, C1}, "cat_mask"); shape(cat_idx, {B, H}, "cat_idx"); shape(c_n, {B, d}, "c_n");
+    shape(Ku, {d, d}, "Ku"); shape(Qu, {d, d}, "Qu"); shape(Fa, {d, d}, "Fa"); shape(Kua, {d, d}, "Kua"); shape(Qua, {d, d}, "Qua");
+    for (int k = 0; k < 5; ++k) shape(grads[k], {d, d}, "weight gradient");
+    for (int k = 5; k < 8; ++k) shape(grads[k], {d}, "bias gradient");
     const size_t nsave = digat_user_ctx_train_save_bytes(B, U, (int)H, (int)C1, d), nws = digat_user_ctx_train_workspace_bytes(B, U, (int)H, (int)C1, d);
-    need((size_t)save.numel() >= nsave, "save buffer of another shape");
+    need(save.is_cuda() && save.device() == Xu.device() && save.scalar_type() == at::kByte && save.is_contiguous() && (size_t)save.numel() >= nsave,
+         "save: the uint8 buffer the forward call returned (same device, same shapes)");
     at::Tensor ws = scratch(Xu, nws), dXu = at::empty_like(Xu), dc = at::empty_like(c_n);
     for (auto& g : grads) f32(g, Xu, "parameter gradient");
     check(digat_user_ctx_bwd(f32(dout, Xu, "dout"), f32(Xu, Xu, "Xu"), bytes(cat_mask, Xu, "cat_mask"), i64(cat_idx, Xu, "cat_idx"), f32(c_n, Xu, "c_n"),
@@ -251,12 +287,15 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_bwd(const at::Tensor& dout, const at
 }
 
 std::tuple<at::Tensor, at::Tensor> dropout_fwd(const at::Tensor& x, double p, int64_t seed) {
+    const c10::DeviceGuard guard(x.device());
     at::Tensor y = at::empty_like(x), mask = at::empty(x.sizes(), x.options().dtype(at::kByte));
     check(digat_dropout_fwd(f32(x, x, "x"), out_f32(y), static_cast<uint8_t*>(mask.data_ptr()), x.numel(), (float)p, (uint32_t)seed, stream_of(x)),
           "digat_dropout_fwd");
     return {y, mask};
 }
 at::Tensor dropout_bwd(const at::Tensor& dy, const at::Tensor& mask, double p) {
+    const c10::DeviceGuard guard(dy.device());
+    need(mask.numel() == dy.numel(), "mask: one byte per element of dy");
     at::Tensor dx = at::empty_like(dy);
     check(digat_dropout_bwd(f32(dy, dy, "dy"), bytes(mask, dy, "mask"), out_f32(dx), dy.numel(), (float)p, stream_of(dy)), "digat_dropout_bwd");
     return dx;

@@ -441,9 +441,16 @@ class StepSink:
     (graphEncoders.py:177-187), so autograd adds four gradients per weight.  With a sink, the first backward call of a kind
     allocates the gradient buffers, the later ones add into them in the library, and only the LAST call of the kind returns them to
     autograd (the others return None for the parameters): AccumulateGrad — and DDP's hooks — fire once per weight with the sum.
-    One sink per forward (``digat_forward_train`` / ``ablation_forward_train`` make it): the count of calls is the forward's own, and
-    every call's output reaches the loss through the c_n / c_u sums.  Should a backward pass end with a kind incomplete (an output
-    that never reached the loss), the pass fails loudly rather than dropping gradients."""
+    One sink per forward, made by ``digat_forward_train`` ONLY (the ablation encoders' ``ablation_forward_train`` passes none: their
+    context calls return per-call gradients and autograd adds them): the count of calls is the forward's own, and every call's output
+    reaches the loss through the c_n / c_u sums.
+    RESTRICTION: the sum is complete only when EVERY context call of the forward takes part in the backward pass.  A partial backward —
+    a loss on ``c_n`` alone, ``torch.autograd.grad`` with respect to inputs that prune a context node — ends with a kind incomplete,
+    and the pass then fails loudly (``_check``) rather than handing autograd a partial sum under the full name.  Such callers set
+    ``encoder.sum_shared_gradients_in_library = False`` (no sink: one gradient per call, summed by autograd; 36 more element-wise
+    launches per step).  Under DistributedDataParallel the shared weights' hooks fire once, at the LAST backward call of their kind
+    (the layer-0 call, i.e. near the end of the backward pass): their bucket's all-reduce overlaps less of the backward than per-call
+    gradients would allow — 2.4 M of the 5.3 M parameters; the per-layer Eq. 8 weights keep their per-layer hooks."""
 
     def __init__(self):
         self.calls, self.done, self.bufs = {}, {}, {}
@@ -682,7 +689,11 @@ def ablation_forward_train(enc, *inputs):
 
 def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding, user_graph,
                         user_category_mask, user_category_indices):
-    """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24)."""
+    """graphEncoders.py:177-187 with dropout live (p, p, p/2 as in :22-24).
+
+    The shared context weights' gradients are summed inside the library (``StepSink``): BOTH returned contexts must reach the loss of
+    the backward pass (they do in ``Model.forward``: logits = user_ctx . news_ctx); for a partial backward set
+    ``enc.sum_shared_gradients_in_library = False`` first (see StepSink)."""
     p, Xn, An, Mn, Xu, Au, cm, ci = _train_inputs(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
                                                   user_graph, user_category_mask, user_category_indices)
     sink = StepSink() if getattr(enc, "sum_shared_gradients_in_library", True) else None

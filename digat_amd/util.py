@@ -14,6 +14,7 @@ The graph encoder is the HIP plugin (``digat_amd.graphEncoders.DIGAT``); nothing
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
 
@@ -571,7 +572,10 @@ def all_gather_scores(local: torch.Tensor, counts: List[int], group=None) -> tor
     return torch.cat([o[:c] for o, c in zip(out, counts)])
 
 
-def freeze_host_heap():
+_HEAP_FROZEN = False
+
+
+def freeze_host_heap(force: bool = False) -> bool:
     """Take the objects alive NOW out of the reach of Python's cyclic garbage collector (``gc.collect(); gc.freeze()``).
 
     A driver loop of this package enqueues hundreds of launches per pass from Python and allocates a few thousand short-lived
@@ -579,10 +583,18 @@ def freeze_host_heap():
     the process — with a corpus's Python-side structures resident that is 75-110 ms on the GPU boxes' hosts (round 5: one such pause
     inside a 60-step training region, 7.06 instead of 6.28 ms per step; the device sat idle at its end).  The reference's MIND_Corpus
     keeps dictionaries of millions of entries: the same pauses, longer.  Frozen objects are still freed by reference counting;
-    they are just never walked again.  Called by ``compute_scores`` and ``trainer.Trainer`` once their inputs exist."""
+    they are just never walked again — which also means cyclic garbage that forms later AMONG them is never reclaimed: a
+    process-global side effect the embedding application may not want.  So (round 6): at most ONCE per process however often the
+    library's entry points are called (``compute_scores`` runs every dev epoch; ``force=True`` freezes again, for a driver that has
+    just built another corpus), and not at all under ``DIGAT_FREEZE_HEAP=0``.  Returns whether this call froze anything."""
+    global _HEAP_FROZEN
+    if os.environ.get("DIGAT_FREEZE_HEAP", "1") == "0" or (_HEAP_FROZEN and not force):
+        return False
     import gc
     gc.collect()
     gc.freeze()
+    _HEAP_FROZEN = True
+    return True
 
 
 def compute_scores(model, dc: DeviceCorpus, batch_size: int, labels: Optional[np.ndarray] = None,

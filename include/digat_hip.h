@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define DIGAT_ABI_VERSION 1
+/* 2 (round 6): digat_news_ctx_bwd / digat_user_ctx_bwd took `accumulate_params` in round 5 and entry points were added without a
+ * bump: a loader built for one version must refuse a library of another (digat_amd/_lib.py does) rather than shift arguments. */
+#define DIGAT_ABI_VERSION 2
 #define DIGAT_MAX_NODES 128
 #define DIGAT_MAX_DEPTH 16
 

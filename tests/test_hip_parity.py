@@ -75,7 +75,7 @@ def run_hip(enc, b, L):
 # --------------------------------------------------------------------------------------------------
 def test_library_loads_on_gpu_box():
     from digat_amd import _lib
-    assert _lib.lib().digat_version() == 1
+    assert _lib.lib().digat_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("M,N,K", [(60, 64, 64), (536, 400, 400), (1024, 400, 400), (4100, 400, 400),
@@ -1322,8 +1322,8 @@ def test_gather_tables_equals_index_select():
     assert torch.equal(out_cand, emb[cand])
 
 
-@pytest.mark.parametrize("neighbors", [5, 8], ids=["N26", "N65"])
-def test_dead_news_nodes_are_skipped_and_never_read(neighbors):
+@pytest.mark.parametrize("neighbors,d", [(5, 400), (8, 400), (9, 400), (5, 800)], ids=["N26", "N65", "N82-pool-fallback", "N26-d800"])
+def test_dead_news_nodes_are_skipped_and_never_read(neighbors, d):
     """Round 5: on the sparse kernel the padding slots of a larger news graph are dead nodes — not projected, scored or written in
     any layer (news_live_flags_kernel).  Against the oracle on graphs that try to break the liveness rule: a padding slot that a
     real node DOES point at (and which itself has no entry: uniform over every node), a real node without any entry, a news
@@ -1331,7 +1331,9 @@ def test_dead_news_nodes_are_skipped_and_never_read(neighbors):
     patterns first (0 x NaN: a dead row that is read would show), and skipping nothing (live_rows off) gives the same bits."""
     from digat_amd import _lib, synthetic
     N = synthetic.news_graph_size(neighbors, 2)
-    B, H, C, d, L = 128, 50, 17, 400, 3
+    # (round 6, ADVICE r05) N = 82 > 68 nodes and d = 800 > 512 channels leave the register-resident pooling for attn_pool_kernel, which
+    # used to multiply EVERY node's row by its weight: a dead node's unwritten row times 0 is NaN when the scratch is poisoned
+    B, H, C, L = 128, 50, 17, 3
     state = synthetic.make_state_dict(d, C, L, seed=161, bias_std=0.05)
     batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=162, isolated_news_rows=(3,))
     A, M = batch["news_graph"], batch["news_graph_mask"]
