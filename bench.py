@@ -101,6 +101,8 @@ def parse_args():
     ap.add_argument("--train-news-encoder", default="table", choices=["table", "msa"],
                     help="--mode train: 'table' = news representations from a trainable table (graph-encoder step only); 'msa' = the "
                          "reference's full step, MSA news encoder on the titles of 64 x (5 x N + H) news per step")
+    ap.add_argument("--fused-user-context", action="store_true",
+                    help="compute_user_graph_context as one launch (csrc/digat_ctxfused.inc; measured at parity with the three launches: opt-in)")
     ap.add_argument("--detail", default=None, help="where the full result document goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--projection", default="auto", choices=["auto", "bf16x6", "bf16x6-pq3", "fp32", "pq-bf16", "pq-bf16-x1", "pq-fp8", "fp16x3"],
                     help="node projections: split-bf16 (fp32-equivalent) on the bf16 matrix cores, or fp32 MFMA; pq-bf16 = BASELINE "
@@ -255,6 +257,7 @@ def build_workload(name, args, D: Dist, impressions, trainable=False):
     model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(D.dev)
     model.graph_encoder.projection_mode = args.projection
+    model.graph_encoder.fused_user_context = bool(getattr(args, "fused_user_context", False))
     dc = util.DeviceCorpus.from_numpy(corpus, D.dev)
     if text_encoder:
         text, mask = synthetic.make_titles(news_num, cfg.max_title_length, cfg.vocabulary_size, seed=7)
@@ -875,6 +878,7 @@ def run_e2e(args, D):
     model.graph_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(D.dev).eval()
     model.graph_encoder.projection_mode = args.projection
+    model.graph_encoder.fused_user_context = bool(getattr(args, "fused_user_context", False))
     dc = util.DeviceCorpus.from_numpy(corpus, D.dev)
     text, mask = synthetic.make_titles(spec.news_num, cfg.max_title_length, cfg.vocabulary_size, seed=7)
     dc.title_text = torch.from_numpy(text).to(torch.int32).to(D.dev)

@@ -53,7 +53,7 @@ class Params(C.Structure):
                 + [("news", LayerParams * DIGAT_MAX_DEPTH), ("user", LayerParams * DIGAT_MAX_DEPTH)]
                 + [(k, _f) for k in ("cand_fold_W", "cand_fold_b", "user_news_fold_W", "user_news_fold_b",
                                      "userAtt_fold_W", "userAtt_fold_b", "featureAffine_wsplit", "cand_fold_wsplit", "gate_wsplit")]
-                + [("ctx_wsplit", _f * (DIGAT_MAX_DEPTH + 1)), ("range_flag", _f)])
+                + [("ctx_wsplit", _f * (DIGAT_MAX_DEPTH + 1)), ("range_flag", _f), ("featureAffine_fsplit", _f)])
 
 
 class DigatHipError(RuntimeError):
@@ -164,12 +164,14 @@ _SIGNATURES = {
     "digat_encoder_fwd_shared": (C.c_int, [C.POINTER(Params)] + [_f] * 10 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
     "digat_user_row_runs": (C.c_int, [_f] * 4 + [C.c_int] * 5 + [_f] * 4 + [C.c_size_t, _f]),
     "digat_profile_xattn_parts": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "digat_split_ctx_fused_bytes": (C.c_size_t, [C.c_int]),
+    "digat_split_ctx_fused_weights": (C.c_int, [_f, C.c_int, _f, _f]),
 }
 _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 XATTN_PARTS = ("twin", "l0", "news", "other")      # digat_profile_xattn_parts: the Eq. 8 launches by kernel
 EXPORTED = tuple(_SIGNATURES)
-ABI_VERSION = 2          # include/digat_hip.h: DIGAT_ABI_VERSION the signature table above was written for
+ABI_VERSION = 3          # include/digat_hip.h: DIGAT_ABI_VERSION the signature table above was written for
 
 
 def lib() -> C.CDLL:

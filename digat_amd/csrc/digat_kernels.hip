@@ -190,6 +190,7 @@ constexpr int TWIN_R = DIGAT_TWIN_R;   // centres with equal adjacency rows serv
 #include "digat_gemm.inc"
 #include "digat_xattn.inc"
 #include "digat_context.inc"
+#include "digat_ctxfused.inc"
 #include "digat_glue.inc"
 #ifdef DIGAT_LAB
 #include "digat_staged.inc"       // Eq. 8 of the user graph from LDS-staged rows: five variants, all measured slower
@@ -421,11 +422,29 @@ int digat_split_proj_weights(const float* W, const float* F1, const float* F2, i
     return launch_split(W, F1, F2, d, 3, d, wsplit, (hipStream_t)stream, 0, format);
 }
 
+size_t digat_split_ctx_fused_bytes(int d) { return d > 0 ? ctxfused_image_bytes(d) : 0; }
+int digat_split_ctx_fused_weights(const float* W, int d, void* image, void* stream) {
+    if (!W || !image || d <= 0) return DIGAT_ERR_ARG;
+    if (d % 8) return DIGAT_ERR_SHAPE;
+    const long total = (long)(ctxfused_image_bytes(d) / 16);
+    hipLaunchKernelGGL(split_weights_ctxfused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, d, (uint4*)image);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
 int digat_split_weights(const float* W, int N, int K, void* wsplit, int format, void* stream) {
     if (!W || !wsplit || N <= 0 || K <= 0) return DIGAT_ERR_ARG;
     return launch_split(W, W, W, N, 1, K, wsplit, (hipStream_t)stream, 0, format);
 }
 
+#ifdef DIGAT_CF_TIMERS
+extern "C" int digat_debug_cf_timers(double* out16) {
+    unsigned long long h[16];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cf_timers), sizeof(h)) != hipSuccess) return DIGAT_ERR_LAUNCH;
+    for (int k = 0; k < 16; ++k) { out16[k] = (double)h[k]; h[k] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cf_timers), h, sizeof(h)) == hipSuccess ? DIGAT_OK : DIGAT_ERR_LAUNCH;
+}
+#endif
 #ifdef DIGAT_GEMM_TIMERS
 int digat_debug_gemm_timers(double* out8) {
     unsigned long long h[8];
@@ -696,6 +715,12 @@ static int encoder_fwd_folded(const digat_params* p, const float* Xn_in, const u
     auto user_ctx_tail = [&](const float* Xu_cur, const float* addend, hipStream_t sq, const int* xgroup = nullptr,
                              const uint8_t* live = nullptr, const float* kq_topic = nullptr, const float* kq_user = nullptr) -> int {
         if (!kq_topic) { kq_topic = kq_t; kq_user = kq_u; }
+        // ONE launch (digat_ctxfused.inc) when the weight version carries the fused image and the shape fits; T, T2 stay unused then
+        if (p->featureAffine_fsplit && fmt == 1 && ctxfused_ok(H, C1, d) && LAB_ENV("DIGAT_CTX_FUSED", 1) != 0) {
+            const CtxFusedArgs fa{Xu_cur, (long)U * d, xgroup, live, U, live ? hist_last : nullptr, kq_topic, kq_user, cat_idx, cat_mask, addend, c_u,
+                                  (const uint4*)p->featureAffine_fsplit, p->featureAffine_b, rflag, B, H, C1, d, sqrtf((float)d), LAB_ENV("DIGAT_CF_DBG", 0)};
+            return launch_user_ctx_fused(fa, sq);
+        }
         int e = launch_topic(Xu_cur, (long)U * d, kq_topic, cat_idx, T, B, H, C1, d, sq, xgroup, live, U, live ? hist_last : nullptr);
         if (e) return e;
         GemmArgs g = gemm_plain(T, d, p->featureAffine_W, p->featureAffine_b, T2, d, B * C1, d, d, 0);

@@ -107,6 +107,12 @@ class DIGAT(GraphEncoder):
         # ``launch_options(...)`` overrides them for the calling THREAD only — nothing here is process-wide.
         self.side_stream = "auto"
         self.live_rows = True
+        # compute_user_graph_context of the folded inference path as ONE launch (csrc/digat_ctxfused.inc: topic pooling, featureAffine
+        # and the SDPA pooling without T / T' leaving the CU; fp16x3 format, H <= 52, 192 < d <= 448, C + 1 <= 20).  OFF by default:
+        # measured at parity with the three launches it replaces (round 6: 0.73 against 0.78 ms of kernel time per 4 096-row pass alone,
+        # the same step time with three passes in flight, 3 % slower at 1 024 rows per pass — DESIGN.md section 4).  Read when the
+        # parameter block is built (a weight version): set it before the first call.
+        self.fused_user_context = False
 
     # ------------------------------------------------------------------ init (graphEncoders.py:76-101)
     def initialize(self):
@@ -256,6 +262,13 @@ class DIGAT(GraphEncoder):
                 for l in range(self.graph_depth + 1):
                     third = self.user_graph_attention_ffn3[l].weight.data_ptr() if l < self.graph_depth else P.userAtt_fold_W
                     P.ctx_wsplit[l] = image(3 * d, d, L_.digat_split_proj_weights, P.user_news_fold_W, P.userAtt_fold_W, third, d)
+                if fmt == _lib.GEMM_F16X3 and self.fused_user_context:
+                    # compute_user_graph_context as one launch (csrc/digat_ctxfused.inc): featureAffine in the fused kernel's lane order
+                    buf = _lib.split_buffer(L_.digat_split_ctx_fused_bytes(d), dev)
+                    _lib.check(L_.digat_split_ctx_fused_weights(self.featureAffine.weight.data_ptr(), d, buf.data_ptr(), _lib.stream_ptr()),
+                               "digat_split_ctx_fused_weights")
+                    P._splits.append(buf)
+                    P.featureAffine_fsplit = buf.data_ptr()
         self._param_block = (ptrs, P, self._fold_key())
         return self._call_block(P)
 
@@ -343,7 +356,7 @@ class DIGAT(GraphEncoder):
         for g in ("news", "user"):
             for f in ("W", "ffn1", "ffn2"):
                 key += tuple(m.weight._version for m in getattr(self, f"{g}_graph_attention_{f}"))
-        return key + (self.featureAffine.weight._version,)
+        return key + (self.featureAffine.weight._version, bool(self.fused_user_context))
 
     def _fold_attention(self):
         """(K x).(Q c + b) = x.(Wf c + bf) with Wf = K^T Q, bf = K^T b, computed by the library itself."""

@@ -37,9 +37,9 @@
 extern "C" {
 #endif
 
-/* 2 (round 6): digat_news_ctx_bwd / digat_user_ctx_bwd took `accumulate_params` in round 5 and entry points were added without a
+/* 3 (round 6; 2 was this round's first bump): digat_params grew featureAffine_fsplit; digat_news_ctx_bwd / digat_user_ctx_bwd took `accumulate_params` in round 5 and entry points were added without a
  * bump: a loader built for one version must refuse a library of another (digat_amd/_lib.py does) rather than shift arguments. */
-#define DIGAT_ABI_VERSION 2
+#define DIGAT_ABI_VERSION 3
 #define DIGAT_MAX_NODES 128
 #define DIGAT_MAX_DEPTH 16
 
@@ -230,7 +230,15 @@ typedef struct digat_params {
                                             activation is at or beyond the format's range (|x| >= 4094 or inf; a NaN input does not raise it — it reaches the outputs as NaN, as in
                                             the reference): the caller zeroes it
                                             before a scoring run and reads it after (digat_amd/util.py re-scores in bf16x6 when set) */
+    const void  *featureAffine_fsplit;   /* optional (round 6), DIGAT_PARAMS_GEMM_F16X3 only: featureAffine.weight as the lane-ordered image of
+                                            digat_split_ctx_fused_weights — with it (and the folded queries) compute_user_graph_context
+                                            (graphEncoders.py:123-134) runs as ONE launch: topic pooling, featureAffine and the SDPA pooling
+                                            without T / T' leaving the CU (H <= 52, 192 < d <= 448, C + 1 <= 20; other shapes keep the three launches) */
 } digat_params;
+
+/* featureAffine.weight [d,d] -> the fused user-context kernel's image (fp16x3 pieces in the kernel's lane order). */
+size_t digat_split_ctx_fused_bytes(int d);
+int digat_split_ctx_fused_weights(const float* W, int d, void* image, void* stream);
 
 /* (K x).(Q c + bQ) = x.(Wf c + bf): fold one ScaledDotProductAttention / user_news pair.
  * K, Q [d,d] nn.Linear weights, bQ [d] or NULL; outputs Wf [d,d] (as an nn.Linear weight), bf [d]. */

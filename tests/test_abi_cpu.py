@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/digat_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTED), "ctypes signature table out of sync with the header"
-    assert L.digat_version() == _lib.ABI_VERSION == 2
+    assert L.digat_version() == _lib.ABI_VERSION == 3
     assert b"workspace" in L.digat_error_string(3)
 
 
@@ -67,7 +67,7 @@ def test_struct_layout_matches_header():
     import ctypes
     from digat_amd import _lib
     assert ctypes.sizeof(_lib.LayerParams) == 9 * 8
-    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 9 * 8 + 7 * 8 + 2 * 8 + 17 * 8 + 8
+    assert ctypes.sizeof(_lib.Params) == 16 + 14 * 8 + 2 * 16 * 9 * 8 + 7 * 8 + 2 * 8 + 17 * 8 + 8 + 8      # ... range_flag, featureAffine_fsplit (round 6)
 
 
 def test_module_mirrors_reference_parameter_names():

@@ -1369,3 +1369,57 @@ def test_dead_news_nodes_are_skipped_and_never_read(neighbors, d):
     close(gn, wn, f"N={N}: news ctx", rtol=2e-5, atol=2e-5)
     close(gu, wu, f"N={N}: user ctx", rtol=2e-5, atol=2e-5)
     assert torch.equal(gn, fn) and torch.equal(gu, fu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [61, 256], ids=["ragged-B61", "B256"])
+def test_user_context_as_one_launch_matches_the_oracle_and_the_three_launches(B):
+    """Round 6: compute_user_graph_context of the folded inference path as ONE launch
+    (csrc/digat_ctxfused.inc: topic pooling -> featureAffine on the matrix cores -> SDPA pooling, four rows per workgroup,
+    T / T' never in HBM).  Against the oracle (graphEncoders.py:123-134 through the whole encoder) and against the three
+    launches it replaces, on a batch that holds what the kernel special-cases: users who read ALL 17 categories (17 slots:
+    the fifth, shared tile and the second pass over the weights), users with an empty history (no unmasked category: the
+    attention is uniform over all C + 1 buckets, the padding bucket included: 1 slot), masks that DISAGREE with what the
+    history holds (a read category masked: no slot, weight 0; an unread category unmasked: a bucket of relu(b)), a history of
+    one item, and a row count that is not a multiple of four."""
+    from digat_amd import synthetic
+    N, H, C, d, L = 10, 50, 17, 400, 2
+    state = synthetic.make_state_dict(d, C, L, seed=171, bias_std=0.05)
+    batch = synthetic.make_encoder_batch(B, N, H, C, d, seed=172, empty_history_rows=(5, 6, 33))
+    rng = np.random.default_rng(173)
+    idx, cm, Au = batch["user_category_indices"], batch["user_category_mask"], batch["user_graph"]
+    # rows 1, 2, 40: all 17 categories read (17 slots; row 2 and row 3 share a workgroup: one with, one without overflow)
+    for b in (1, 2, 40):
+        cats = np.concatenate([np.arange(C), rng.integers(0, C, size=H - C)])
+        rng.shuffle(cats)
+        ug, m, ix = synthetic.build_user_graphs(cats[None, :].astype(np.int64), np.array([H]), C)
+        idx[b], cm[b], Au[b] = ix[0], m[0], ug[0]
+    # row 8: a read category masked, an unread one unmasked; row 9: EVERY bucket masked although the history is full (uniform over
+    # all 18 buckets: the read categories + the padding bucket need slots); row 10: one item
+    read = np.flatnonzero(cm[8][:C])
+    unread = np.flatnonzero(~cm[8][:C])
+    if len(read) and len(unread):
+        cm[8][read[0]] = False
+        cm[8][unread[0]] = True
+    cm[9][:] = False
+    ug, m, ix = synthetic.build_user_graphs(rng.integers(0, C, size=(1, H)).astype(np.int64), np.array([1]), C)
+    idx[10], cm[10], Au[10] = ix[0], m[0], ug[0]
+    with torch.no_grad():
+        wn, wu = O.encoder_forward(O.as_params(state), L, *O.batch_tensors(batch))
+    keys = ("news_graph_embeddings", "news_graph", "news_graph_mask", "user_news_embedding", "user_graph",
+            "user_category_mask", "user_category_indices")
+    args = [to_dev(batch)[k] for k in keys]
+    enc = make_encoder(state, N, H, C, d, L)
+    enc.projection_mode = "fp16x3"              # the fused kernel is the fp16x3 format's (what "auto" resolves to in util / bench)
+    enc.fused_user_context = True               # opt-in (measured at parity with the three launches: DESIGN.md section 4)
+    assert enc.gemm_format() == 1
+    with torch.no_grad():
+        fn, fu = enc(*args)
+        assert enc._param_block[1].featureAffine_fsplit, "the fused image was not built: the test would compare the old path with itself"
+        enc.fused_user_context = False
+        tn, tu = enc(*args)
+        assert not enc._param_block[1].featureAffine_fsplit
+    close(fu, wu, "fused user ctx vs oracle", rtol=2e-5, atol=2e-5)
+    close(fn, wn, "news ctx vs oracle", rtol=2e-5, atol=2e-5)
+    close(fu, tu, "fused vs three launches", rtol=2e-6, atol=2e-6)
+    assert not torch.equal(fu, tu), "the two paths sum in different orders: identical bits mean the switch does nothing"
