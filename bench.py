@@ -652,18 +652,26 @@ def rooflines(W, run, args):
                 "launches": v["launches"]}
 
     def roof(kind):
+        """`frac` / `achieved` / `avg_launch_ms` are the SOLO figures (round 6): the kind's launches on a single stream
+        (the untimed profiling pass): the only figure a kernel-trace of the same command reproduces.  The durations of the same
+        launches INSIDE the timed region, where three passes share the chip, are kept as `*_overlapped`: they measure sharing
+        (more passes in flight = higher throughput and LONGER individual launches), not the kernel."""
         out = roof_of(kind, kinds[kind])
         iso = prof_iso.get(kind)
         if iso and iso["launches"] > 0:
             o2 = roof_of(kind, iso)
-            out["isolated_achieved"], out["isolated_frac"] = o2["achieved"], o2["frac"]
+            out["frac_overlapped"], out["achieved_overlapped"], out["avg_launch_ms_overlapped"] = out["frac"], out["achieved"], out["avg_launch_ms"]
+            out["frac"], out["achieved"], out["avg_launch_ms"] = o2["frac"], o2["achieved"], o2["avg_launch_ms"]
+            out["isolated_achieved"], out["isolated_frac"] = o2["achieved"], o2["frac"]          # the names of rounds 3-5, same values as frac / achieved
             if "fp32_equivalent_tflops" in o2:
+                out["fp32_equivalent_tflops_overlapped"] = out.get("fp32_equivalent_tflops")
+                out["fp32_equivalent_tflops"] = o2["fp32_equivalent_tflops"]
                 out["isolated_fp32_equivalent_tflops"] = o2["fp32_equivalent_tflops"]
+                out["fp32_equivalent_frac_of_fp32_mfma_peak"] = o2["fp32_equivalent_frac_of_fp32_mfma_peak"]
             out["isolated_avg_launch_ms"] = o2["avg_launch_ms"]
-            out["note"] = ("achieved/frac: launch durations inside the timed region, where three batches are in flight and each has "
-                           "its news-graph / user-context kernels on a side stream: a launch's duration there includes the time it "
-                           "shares the chip (more batches in flight = higher throughput and LONGER individual launches); "
-                           "isolated_*: the same launches on a single stream (untimed pass)")
+            out["note"] = ("frac / achieved / avg_launch_ms: the kind's launches on a single stream (solo; reproducible from profiles/*_solo_kernels.txt); "
+                           "*_overlapped: the same launches inside the timed region with three passes in flight — a launch's duration there "
+                           "includes the time it shares the chip: a measure of sharing, not of the kernel")
         return out
 
     rx = None
@@ -689,6 +697,9 @@ def rooflines(W, run, args):
                 e["isolated_achieved"] = vi["work"] / (vi["ms"] * 1e-3) / 1e9
                 e["isolated_frac"] = e["isolated_achieved"] / HBM_PEAK_GBS
                 e["isolated_algorithmic_bytes_per_launch"] = vi["work"] / vi["launches"]
+                # frac := the solo fraction (as in roof()); the in-region figures keep the *_overlapped names
+                e["frac_overlapped"], e["achieved_overlapped"], e["avg_launch_us_overlapped"] = e["frac"], e["achieved"], e["avg_launch_us"]
+                e["frac"], e["achieved"], e["avg_launch_us"] = e["isolated_frac"], e["isolated_achieved"], e["isolated_avg_launch_us"]
             if name in part_symbol:
                 symbols["xattn/" + name] = part_symbol[name]
                 t = pmc_traffic("xattn/" + name)
@@ -971,24 +982,26 @@ def compact_line(out):
                                        "backend", "ranks_in_process_group") if k in cfg}
     roof = out.get("roofline")
     if roof:
-        r = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "isolated_frac", "isolated_achieved", "avg_launch_ms",
-                        "isolated_avg_launch_ms", "launches"))
+        r = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_overlapped", "achieved_overlapped", "avg_launch_ms",
+                        "avg_launch_ms_overlapped", "launches"))
+        r["frac_is"] = "solo: the kind's launches on a single stream; *_overlapped: inside the timed region, three passes sharing the chip"
         t = roof.get("traffic")
         r["traffic"] = None if not t else _r(float(t["bytes_per_launch"]), 0)
         if t:
-            r["traffic_unit"] = "HBM bytes per launch, 2*FETCH_SIZE+WRITE_SIZE (%s)" % t.get("source", "profiles/")
+            r["traffic_unit"] = ("HBM bytes per launch, 2*FETCH_SIZE+WRITE_SIZE (%s; factors 2.0 / 1.0 calibrated on known byte counts in this "
+                                 "kernel's access shapes: profiles/r06_fetch_calib.json)" % t.get("source", "profiles/"))
         for k in ("algorithmic_flops_per_launch", "executed_flops_per_launch"):
             if k in roof:
                 r[k] = _r(float(roof[k]), 0)
         c["roofline"] = r
     rx = out.get("roofline_xattn")
     if rx:
-        x = pick(rx, ("bound", "achieved", "peak", "unit", "frac", "isolated_frac", "isolated_achieved"))
+        x = pick(rx, ("bound", "achieved", "peak", "unit", "frac", "frac_overlapped", "achieved_overlapped"))
         x["parts"] = {}
         for name, e in (rx.get("parts") or {}).items():
             x["parts"][name] = {"us": _r(e["avg_launch_us"], 1), "frac": _r(e["frac"], 3),
-                                "solo_us": _r(e.get("isolated_avg_launch_us"), 1) if e.get("isolated_avg_launch_us") else None,
-                                "solo_frac": _r(e.get("isolated_frac"), 3) if e.get("isolated_frac") else None,
+                                "us_overlapped": _r(e.get("avg_launch_us_overlapped"), 1) if e.get("avg_launch_us_overlapped") else None,
+                                "frac_overlapped": _r(e.get("frac_overlapped"), 3) if e.get("frac_overlapped") else None,
                                 "alg_MB": _r(e.get("isolated_algorithmic_bytes_per_launch", e["algorithmic_bytes_per_launch"]) / 1e6, 1),
                                 "pmc_MB": _r(e["traffic"] / 1e6, 1) if e.get("traffic") else None}
         c["roofline_xattn"] = x

@@ -62,6 +62,8 @@ def test_bench_single_gpu_prints_the_contract_line(tmp_path):
     assert abs(line["value"] - short["value"]) <= 1e-3 * line["value"]
     roof = line["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and 0 < roof["frac"] < 1
+    # round 6: `frac` is the SOLO fraction (single stream: what a kernel trace reproduces); the in-region figure keeps its own name
+    assert roof["frac"] == roof["isolated_frac"] and 0 < roof["frac_overlapped"] < 1 and roof["avg_launch_ms_overlapped"] > 0
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
     assert line["auc_match"]["max_abs_metric_diff"] <= line["auc_match"]["tolerance"] and line["valid"] is True
@@ -72,6 +74,7 @@ def test_bench_single_gpu_prints_the_contract_line(tmp_path):
     for name in ("twin", "l0", "news"):
         e = rx["parts"][name]
         assert e["launches"] > 0 and e["algorithmic_bytes_per_launch"] > 0 and 0 < e["isolated_frac"] < 1
+        assert e["frac"] == e["isolated_frac"] and 0 < e["frac_overlapped"] < 1
     # layer 0 of grouped rows reads each GROUP's rows once: its algorithmic bytes are far below a layer >= 1 launch's
     assert rx["parts"]["l0"]["algorithmic_bytes_per_launch"] < 0.6 * rx["parts"]["twin"]["isolated_algorithmic_bytes_per_launch"]
     assert line["setup_ms"] > 0 and line["config"]["news_num"] == 2048
@@ -174,6 +177,44 @@ def test_bench_train_mode_two_ranks_ddp():
     # the gradient all-reduce as DistributedDataParallel times it, and the ranks that really rendezvoused
     assert line["ranks_in_process_group"] == 2 and line["backend"] == "gloo"
     assert line["ddp_timers"] and ("avg_backward_comm_time" in line["ddp_timers"] or "error" in line["ddp_timers"])
+
+
+def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
+    """Round 6: the driver's 8-GPU scaling run has never had hardware.  The same command line — ``bench.py --gpus 8``,
+    the launcher started by bench.py itself before any GPU call — with all eight ranks on cuda:0 and gloo collectives
+    (DIGAT_BENCH_TEST_SHARED_GPU): rank count, row shards, ports, the all-gather of the scores and the summed line, before the first
+    real 8-GPU lease.  Eight ranks, eight shards, every rank's rows in the sum."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DIGAT_BENCH_TEST_SHARED_GPU="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--impressions", "300", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["ranks_in_process_group"] == 8 and line["config"]["backend"] == "gloo"
+    assert "dp8" in line["config"]["parallelism"] and line["config"]["N"] == 26            # BASELINE configs[3]: MIND-large shapes at N > 1
+    per = line["per_rank_impressions_per_s"]
+    assert len(per) == 8 and all(v > 0 for v in per) and len(line["devices"]) == 8
+    assert len(line["all_gather_ms_by_rank"]) == 8 and all(v > 0 for v in line["all_gather_ms_by_rank"])
+    assert line["value"] <= sum(per) * 1.001                       # the ranks' rows over the slowest rank's clock
+    assert line["auc_match"]["max_abs_metric_diff"] <= 1e-4
+    n1 = line["n1_same_workload"]
+    assert n1["value"] > 0 and abs(line["scaling_efficiency"] - line["value"] / (8 * n1["value"])) < 1e-5
+
+
+def test_bench_train_mode_eight_ranks_ddp_rehearsal():
+    """... and --mode train with eight DistributedDataParallel ranks on the one GPU (gloo): the gradient buckets of eight ranks meet."""
+    env = dict(os.environ, DIGAT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29735", "bench.py", "--gpus", "8", "--mode", "train", "--steps", "2", "--warmup", "1",
+           "--impressions", "400", "--news", "2048"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _last_json_line(res.stdout)
+    import math
+    assert line["n_gpus"] == 8 and line["unit"] == "rows/s" and line["value"] > 0 and "ddp8" in line["config"]["parallelism"]
+    assert math.isfinite(line["final_loss"]) and line["ranks_in_process_group"] == 8 and line["backend"] == "gloo"
 
 
 def test_bench_train_mode_with_the_msa_news_encoder():

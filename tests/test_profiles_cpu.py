@@ -85,3 +85,34 @@ def test_solo_fractions_follow_from_the_solo_kernel_table():
         assert abs(e["isolated_avg_launch_us"] - avg_us) <= 0.15 * avg_us, (name, e["isolated_avg_launch_us"], avg_us)
         frac = e.get("isolated_algorithmic_bytes_per_launch", e["algorithmic_bytes_per_launch"]) / (avg_us * 1e-6) / 8e12
         assert abs(frac - e["isolated_frac"]) <= 0.15 * frac + 0.01, (name, frac, e["isolated_frac"])
+
+
+def test_fetch_size_correction_is_calibrated_on_known_byte_counts():
+    """Round 6: the `traffic` figures are 2 x FETCH_SIZE + WRITE_SIZE.  The factor is not applied blindly any
+    more: profiles/r06_fetch_calib.json holds it measured on known byte counts in every access shape of the product kernels
+    (tools/exp/fetch_calib.hip): streamed and row-shaped float4 loads, LDS-DMA, the GEMM's 128-byte row pieces, gathered rows."""
+    doc = json.load(open(os.path.join(PROFILES, "r06_fetch_calib.json")))
+    shapes = doc["shapes"]
+    assert {"stream_f4", "stream_dma", "rows128_dma", "rows1600_f4", "rows1600_f4g", "store_f4"} <= set(shapes)
+    for name, v in shapes.items():
+        lo, hi = (0.98, 1.02) if name == "store_f4" else (1.7, 2.02)       # reads: half-counted, up to 12 % of line straddling on top
+        assert lo <= v["factor"] <= hi, (name, v["factor"])
+        assert abs(v["known_bytes"] / (v["counter_kb"] * 1024.0) - v["factor"]) < 1e-9
+
+
+def test_counter_bytes_bracket_the_algorithmic_bytes_of_every_hot_kernel():
+    """counter bytes >= 0.95 x algorithmic AND <= 1.6 x algorithmic for the kernels whose algorithmic bytes are counted on the device
+    (the three Eq. 8 kernels): a blind factor of two on a kernel that does not deserve it would show here."""
+    r, pmc_path = _newest("{r}_final_pmc.json")
+    bench_path = os.path.join(PROFILES, f"{r}_final_bench.json")
+    if not os.path.exists(bench_path):
+        pytest.skip(f"profiles/{r}_final_bench.json not collected")
+    parts = (_bench_doc(bench_path).get("roofline_xattn") or {}).get("parts")
+    if not parts:
+        pytest.skip("bench document predates the per-kernel Eq. 8 accounting")
+    kernels = json.load(open(pmc_path))["kernels"]
+    symbol = {"twin": "xattn_sparse_twin", "l0": "xattn_sparse_l0", "news": "xattn_small_lds"}
+    for name, sym in symbol.items():
+        counted = [v for k, v in kernels.items() if sym in k][0]["hbm_bytes_mean"]
+        alg = parts[name].get("isolated_algorithmic_bytes_per_launch", parts[name]["algorithmic_bytes_per_launch"])
+        assert 0.95 * alg <= counted <= 1.6 * alg, f"{name}: counted {counted / 1e6:.1f} MB vs algorithmic {alg / 1e6:.1f} MB"

@@ -43,7 +43,7 @@ def main():
             print(f"{name:16s} ms/step {j['ms_per_step']:.4f}  imp/s {j['value']:.0f}  lanes {j['batches_in_flight']}  solo "
                   + " ".join(f"{k}={v:.3f}" for k, v in iso.items())
                   + "  | eq8 solo us " + " ".join(f"{k}={v.get('isolated_avg_launch_us', 0):.1f}" for k, v in parts.items())
-                  + "  | in-region us " + " ".join(f"{k}={v['avg_launch_us']:.1f}" for k, v in parts.items()), flush=True)
+                  + "  | in-region us " + " ".join(f"{k}={v.get('avg_launch_us_overlapped', v['avg_launch_us']):.1f}" for k, v in parts.items()), flush=True)
 
 
 if __name__ == "__main__":
