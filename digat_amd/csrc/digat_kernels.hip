@@ -193,7 +193,7 @@ constexpr int TWIN_R = DIGAT_TWIN_R;   // centres with equal adjacency rows serv
 #include "digat_ctxfused.inc"
 #include "digat_glue.inc"
 #ifdef DIGAT_LAB
-#include "digat_staged.inc"       // Eq. 8 of the user graph from LDS-staged rows: five variants, all measured slower
+#include "digat_staged.inc"       // Eq. 8 of the user graph from LDS-staged rows: five variants, all measured slower (docs/REJECTED.md, row 7)
 #else
 // the product library carries the evidence (profiles/), not the code path
 struct PlanBuffers {};
