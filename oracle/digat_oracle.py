@@ -92,10 +92,17 @@ def scaled_dot_attention(p: Params, name: str, feature: torch.Tensor, query: tor
 # ------------------------------------------------------------------------------------------
 # a3: news-graph context (graphEncoders.py:109-114), eval mode (dropout__ is identity)
 # ------------------------------------------------------------------------------------------
-def news_graph_context(p: Params, X: torch.Tensor, node_mask: torch.Tensor) -> torch.Tensor:
+def _keep(x: torch.Tensor, drop, frac: float) -> torch.Tensor:
+    """Train mode: ``drop(x, frac)`` is the caller's dropout at rate ``frac * dropout_rate`` (graphEncoders.py:22-24: ``dropout`` and
+    ``dropout_`` are the full rate, ``dropout__`` half of it); ``None`` = eval mode (identity).  The hook is called once per
+    dropout site, in the reference's order of evaluation."""
+    return x if drop is None else drop(x, frac)
+
+
+def news_graph_context(p: Params, X: torch.Tensor, node_mask: torch.Tensor, drop=None) -> torch.Tensor:
     local = X[:, 0]
     glob = scaled_dot_attention(p, "candidate_attention", X, local, node_mask)
-    gate = torch.sigmoid(_linear(torch.cat([local, glob], dim=1), p, "news_graph_W"))
+    gate = torch.sigmoid(_keep(_linear(torch.cat([local, glob], dim=1), p, "news_graph_W"), drop, 0.5))   # dropout__ (:111)
     return gate * local + (1 - gate) * glob
 
 
@@ -116,9 +123,9 @@ def topic_pooling(p: Params, Xu: torch.Tensor, cat_idx: torch.Tensor, c_n: torch
 
 
 def user_graph_context(p: Params, Xu: torch.Tensor, cat_mask: torch.Tensor, cat_idx: torch.Tensor,
-                       c_n: torch.Tensor, H: int) -> torch.Tensor:
+                       c_n: torch.Tensor, H: int, drop=None) -> torch.Tensor:
     topics = topic_pooling(p, Xu, cat_idx, c_n, H)
-    topics = F.relu(_linear(topics, p, "featureAffine")) + topics             # :131
+    topics = _keep(F.relu(_linear(topics, p, "featureAffine")) + topics, drop, 1.0)   # :131 (dropout)
     return scaled_dot_attention(p, "userAttention", topics, c_n, cat_mask)    # :133
 
 
@@ -126,7 +133,7 @@ def user_graph_context(p: Params, Xu: torch.Tensor, cat_mask: torch.Tensor, cat_
 # a1 / a2: Eq. 8 dual-interaction GAT layer (graphEncoders.py:143-154 / :163-174), eval mode
 # ------------------------------------------------------------------------------------------
 def cross_graph_attention(p: Params, graph: str, layer: int, X: torch.Tensor, adj: torch.Tensor,
-                          ctx: torch.Tensor, return_alpha: bool = False):
+                          ctx: torch.Tensor, return_alpha: bool = False, drop=None):
     """Unfused, exactly as the reference evaluates it: materialises [B,n,n,d].
 
     K1 (ffn1) is indexed by the neighbour j, K2 (ffn2) by the centre i, softmax over j (E5);
@@ -134,6 +141,7 @@ def cross_graph_attention(p: Params, graph: str, layer: int, X: torch.Tensor, ad
     """
     B, n, d = X.shape
     pre = f"{graph}_graph_attention_"
+    X = _keep(X, drop, 0.5)                                                   # dropout__ (:145 / :165): the residual uses the dropped input
     h = _linear(X, p, f"{pre}W.{layer}")
     K1 = _linear(X, p, f"{pre}ffn1.{layer}").unsqueeze(1)                     # [B,1,n,d]
     K2 = _linear(X, p, f"{pre}ffn2.{layer}").unsqueeze(2)                     # [B,n,1,d]
@@ -141,39 +149,85 @@ def cross_graph_attention(p: Params, graph: str, layer: int, X: torch.Tensor, ad
     s = F.linear(F.relu(K3 + K1 + K2), p[f"{pre}a.{layer}.weight"]).squeeze(3)  # [B,n,n]
     e = F.leaky_relu(s, 0.2)
     alpha = F.softmax(e.masked_fill(adj == 0, MASK_FILL), dim=2)
-    out = F.relu(torch.bmm(alpha, h)) + X
+    out = F.relu(torch.bmm(_keep(alpha, drop, 1.0), h)) + X                   # dropout_ on alpha (:152 / :172)
     return (out, alpha) if return_alpha else out
 
 
 # ------------------------------------------------------------------------------------------
 # a5: orchestration (graphEncoders.py:177-198), eval mode
 # ------------------------------------------------------------------------------------------
-def user_nodes(p: Params, user_news_embedding: torch.Tensor) -> torch.Tensor:
+def user_nodes(p: Params, user_news_embedding: torch.Tensor, drop=None) -> torch.Tensor:
     B = user_news_embedding.shape[0]
-    topic = p["topic_node_embedding"].unsqueeze(0).expand(B, -1, -1)
+    topic = _keep(p["topic_node_embedding"].unsqueeze(0).expand(B, -1, -1), drop, 0.5)    # dropout__ (:179)
     return torch.cat([user_news_embedding, topic], dim=1)                     # [history | topics] (E4)
 
 
 def encoder_inference(p: Params, depth: int, Xn, An, Mn, user_news_embedding, Au, cat_mask, cat_idx,
-                      c_n, trace: "List | None" = None):
+                      c_n, trace: "List | None" = None, drop=None, Xu=None):
     H = user_news_embedding.shape[1]
-    Xu = user_nodes(p, user_news_embedding)
-    c_u = user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H)
+    if Xu is None:
+        Xu = user_nodes(p, user_news_embedding)
+    c_u = user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H, drop)
     for i in range(depth):
-        Xn_next = cross_graph_attention(p, "news", i, Xn, An, c_u)
-        Xu_next = cross_graph_attention(p, "user", i, Xu, Au, c_n)
+        Xn_next = cross_graph_attention(p, "news", i, Xn, An, c_u, drop=drop)
+        Xu_next = cross_graph_attention(p, "user", i, Xu, Au, c_n, drop=drop)
         Xn, Xu = Xn_next, Xu_next
-        c_n = c_n + news_graph_context(p, Xn, Mn)
-        c_u = c_u + user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H)     # uses the UPDATED c_n
+        c_n = c_n + news_graph_context(p, Xn, Mn, drop)
+        c_u = c_u + user_graph_context(p, Xu, cat_mask, cat_idx, c_n, H, drop)     # uses the UPDATED c_n
         if trace is not None:
             trace.append((Xn, Xu, c_n, c_u))
     return c_n, c_u
 
 
 def encoder_forward(p: Params, depth: int, Xn, An, Mn, user_news_embedding, Au, cat_mask, cat_idx,
-                    trace: "List | None" = None):
-    c_n0 = news_graph_context(p, Xn, Mn)                                      # :180
-    return encoder_inference(p, depth, Xn, An, Mn, user_news_embedding, Au, cat_mask, cat_idx, c_n0, trace)
+                    trace: "List | None" = None, drop=None):
+    """``drop`` (train mode): the dropout hook of ``_keep``, called in the order of graphEncoders.py:177-187 — the topic nodes (:179),
+    then per function as the reference evaluates it."""
+    Xu = user_nodes(p, user_news_embedding, drop)                             # :179
+    c_n0 = news_graph_context(p, Xn, Mn, drop)                                # :180
+    return encoder_inference(p, depth, Xn, An, Mn, user_news_embedding, Au, cat_mask, cat_idx, c_n0, trace, drop, Xu)
+
+
+# ------------------------------------------------------------------------------------------
+# train mode: the dropout generator of the HIP path, restated (digat_amd/csrc/digat_train.inc, dropout_fwd_kernel)
+# ------------------------------------------------------------------------------------------
+def _hash32(x: np.ndarray) -> np.ndarray:
+    m = np.uint64(0xFFFFFFFF)
+    x = x & m
+    x = x ^ (x >> np.uint64(16)); x = (x * np.uint64(0x7FEB352D)) & m
+    x = x ^ (x >> np.uint64(15)); x = (x * np.uint64(0x846CA68B)) & m
+    return x ^ (x >> np.uint64(16))
+
+
+def hash_dropout_keep(n: int, p: float, seed: int) -> np.ndarray:
+    """keep[e] of a dropout over n < 2^32 elements in flat (row-major) order: a counter-based hash of (seed, e) against
+    floor(float32(p) * 2^32).  Dropout masks are the one thing a reimplementation cannot share with the reference (torch's Philox
+    stream); restating the HIP path's generator lets the REFERENCE's autograd run a training step under the very masks the kernels
+    draw (oracle/make_golden.py train_step_dropout)."""
+    assert 0 <= n < 2 ** 32
+    e = np.arange(n, dtype=np.uint64)
+    inner = _hash32(np.array([seed], dtype=np.uint64))[0]
+    h = _hash32(((e * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)) + inner)
+    thr = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    return h >= thr
+
+
+def hash_dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    """x * keep / (1 - p) in fp32, as the kernels evaluate it (scale = 1 / (1 - float32(p)) rounded to fp32)."""
+    keep = torch.from_numpy(hash_dropout_keep(x.numel(), p, seed)).view(x.shape)
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    return torch.where(keep, x * scale, torch.zeros_like(x))
+
+
+class SeedTape:
+    """Dropout hook for ``encoder_forward(drop=...)``: site k of a forward pass uses seed ``first + k``."""
+
+    def __init__(self, rate: float, first: int = 1001):
+        self.rate, self.next = float(rate), int(first)
+
+    def __call__(self, x: torch.Tensor, frac: float) -> torch.Tensor:
+        seed, self.next = self.next, self.next + 1
+        return hash_dropout(x.contiguous(), self.rate * frac, seed)
 
 
 # ------------------------------------------------------------------------------------------
@@ -186,7 +240,7 @@ def row_logits(p: Params, depth: int, user_news_embedding, Au, cat_mask, cat_idx
     return (user_rep * news_rep).sum(dim=1)
 
 
-def training_logits(p: Params, depth: int, user_news_embedding, Au, cat_mask, cat_idx, Xn, An, Mn):
+def training_logits(p: Params, depth: int, user_news_embedding, Au, cat_mask, cat_idx, Xn, An, Mn, drop=None):
     """model.py:54-77 from the encoder inputs on: [B, 1+neg] candidates per user, user tensors
     expanded per candidate, dot-product logits.  Xn [B,K,N,d], An [B,K,N,N], Mn [B,K,N]."""
     B, K = Xn.shape[:2]
@@ -196,7 +250,7 @@ def training_logits(p: Params, depth: int, user_news_embedding, Au, cat_mask, ca
 
     news_rep, user_rep = encoder_forward(
         p, depth, Xn.reshape(B * K, *Xn.shape[2:]), An.reshape(B * K, *An.shape[2:]),
-        Mn.reshape(B * K, -1), expand(user_news_embedding), expand(Au), expand(cat_mask), expand(cat_idx))
+        Mn.reshape(B * K, -1), expand(user_news_embedding), expand(Au), expand(cat_mask), expand(cat_idx), drop=drop)
     return (user_rep.view(B, K, -1) * news_rep.view(B, K, -1)).sum(dim=2)
 
 

@@ -284,6 +284,60 @@ def fixture_train_step(ge):
          g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
 
 
+def fixture_train_step_dropout(ge):
+    """(v') the same step with dropout LIVE (rate 0.2): the reference's three nn.Dropout modules (graphEncoders.py:22-24) are swapped
+    for modules that draw their masks from the HIP path's counter-hash generator (oracle.digat_oracle.hash_dropout), site k of the
+    forward pass with seed 1001 + k — so the reference's own autograd yields the loss and every gradient under exactly the masks
+    the kernels draw when digat_amd.training._seed hands out 1001, 1002, ... (tests/test_hip_training.py)."""
+    from oracle import digat_oracle as O
+    B, K, N, H, C, d, L = 3, 5, 4, 10, 5, 32, 2
+    rate = 0.2
+    state = synthetic.make_state_dict(d, C, L, seed=51, bias_std=0.05)
+    flat = synthetic.make_encoder_batch(B * K, N, H, C, d, seed=52)
+    users = synthetic.make_encoder_batch(B, N, H, C, d, seed=53)
+    enc = reference_encoder(ge, N, H, C, d, L, state, dropout=rate).train()
+    tape = O.SeedTape(rate, first=1001)
+
+    class TapeDropout(torch.nn.Module):
+        def __init__(self, frac):
+            super().__init__()
+            self.frac = frac
+
+        def forward(self, x):
+            return tape(x, self.frac) if self.training else x
+
+    enc.dropout, enc.dropout_, enc.dropout__ = TapeDropout(1.0), TapeDropout(1.0), TapeDropout(0.5)
+    Xn = T(flat["news_graph_embeddings"]).requires_grad_(True)
+    ue = T(users["user_news_embedding"]).requires_grad_(True)
+
+    def expand(t):                                                          # model.py:64-71
+        return t.unsqueeze(1).expand(B, K, *t.shape[1:]).contiguous().view(B * K, *t.shape[1:])
+
+    n, u = enc(Xn, T(flat["news_graph"]), T(flat["news_graph_mask"]), expand(ue),
+               expand(T(users["user_graph"])), expand(T(users["user_category_mask"])),
+               expand(T(users["user_category_indices"])))
+    logits = (u.view(B, K, d) * n.view(B, K, d)).sum(dim=2)
+    loss = (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
+    loss.backward()
+    grads = {"g_" + k: v.grad.numpy() for k, v in enc.named_parameters()}
+    # the oracle's train mode (the same hook) must agree with the reference it restates
+    p = O.as_params(state)
+    lo = O.training_logits(p, L, T(users["user_news_embedding"]), T(users["user_graph"]), T(users["user_category_mask"]),
+                           T(users["user_category_indices"]), T(flat["news_graph_embeddings"]).view(B, K, N, d),
+                           T(flat["news_graph"]).view(B, K, N, N), T(flat["news_graph_mask"]).view(B, K, N),
+                           drop=O.SeedTape(rate, first=1001))
+    assert float((lo - logits.detach()).abs().max()) < 1e-5, "oracle train mode drifted from the reference"
+    save("train_step_dropout.npz", meta=np.array([B, K, N, H, C, d, L]), dropout_rate=np.float64(rate),
+         first_seed=np.int64(1001), sites=np.int64(tape.next - 1001),
+         in_news_graph_embeddings=flat["news_graph_embeddings"], in_news_graph=flat["news_graph"],
+         in_news_graph_mask=flat["news_graph_mask"], in_user_news_embedding=users["user_news_embedding"],
+         in_user_graph=users["user_graph"], in_user_category_mask=users["user_category_mask"],
+         in_user_category_indices=users["user_category_indices"],
+         **{"w_" + k: v for k, v in state.items()},
+         out_logits=logits.detach().numpy(), out_loss=loss.detach().numpy(),
+         g_in_news_graph_embeddings=Xn.grad.numpy(), g_in_user_news_embedding=ue.grad.numpy(), **grads)
+
+
 def grad_digest(name, g):
     """Compact, order-sensitive digest of one gradient tensor: its L2 norm, its dot product with a fixed pseudo-random
     probe (seeded by the parameter name), and every ``stride``-th element.  21 MB of production-shape gradients would not
@@ -597,7 +651,7 @@ def main():
     ge, ev = import_reference()
     print("reference imported from", REFERENCE)
     jobs = {"tiny": lambda: fixture_tiny(ge), "edges": lambda: fixture_edges(ge), "train_step": lambda: fixture_train_step(ge),
-            "train_step_default": lambda: fixture_train_step_default(ge), "devset": lambda: fixture_devset(ge, ev, ("devset_tiny", "devset_default")),
+            "train_step_default": lambda: fixture_train_step_default(ge), "train_step_dropout": lambda: fixture_train_step_dropout(ge), "devset": lambda: fixture_devset(ge, ev, ("devset_tiny", "devset_default")),
             "devset_large": lambda: fixture_devset(ge, ev, ("devset_large",)), "devset_stress": lambda: fixture_devset(ge, ev, ("devset_stress",)),
             "default": lambda: fixture_default(ge), "ablations": lambda: fixture_ablations(ge),
             "ablation_train": lambda: fixture_ablation_train(ge), "msa": fixture_msa,

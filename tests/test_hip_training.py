@@ -72,6 +72,32 @@ def test_training_step_matches_reference_autograd():
         close(p.grad, fx["g_" + name], "grad " + name)
 
 
+def test_training_step_with_dropout_live_matches_reference_autograd_under_the_same_masks(monkeypatch):
+    """Dropout LIVE (rate 0.2), held to the reference: tests/golden/train_step_dropout.npz is the reference's autograd with its
+    nn.Dropout modules drawing the library's counter-hash masks, seed 1001 + site in the order of graphEncoders.py:177-187.  Here
+    ``training._seed`` hands out the same seeds: every fused dropout (layer inputs, alpha, the gate, the pooled topics, the topic
+    nodes) must land on the same elements with the same scale, forward and backward."""
+    from digat_amd import training
+    fx = load_golden("train_step_dropout.npz")
+    tape = iter(range(int(fx["first_seed"]), int(fx["first_seed"]) + 1000))
+    monkeypatch.setattr(training, "_seed", lambda: next(tape))
+    for use_ext in (True, False):
+        tape = iter(range(int(fx["first_seed"]), int(fx["first_seed"]) + 1000))
+        enc, t, outs, dims = build(fx, dropout=float(fx["dropout_rate"]))
+        if not use_ext:
+            monkeypatch.setattr(training._lib, "ext", lambda: None)
+        logits, loss, Xn, ue = run_step(enc, t, dims)
+        torch.cuda.synchronize()
+        assert next(tape) - int(fx["first_seed"]) == int(fx["sites"]), "a dropout site was added, dropped or reordered"
+        close(logits, outs["logits"], "logits", rtol=1e-5, atol=1e-5)
+        close(loss, outs["loss"], "loss", rtol=1e-5, atol=1e-6)
+        close(Xn.grad, fx["g_in_news_graph_embeddings"], "d news_graph_embeddings")
+        close(ue.grad, fx["g_in_user_news_embedding"], "d user_news_embedding")
+        for name, p in enc.named_parameters():
+            assert p.grad is not None, name
+            close(p.grad, fx["g_" + name], "grad " + name)
+
+
 def build_default(dropout=0.0):
     """train_step_default.npz: the production shapes (N=10, U=67, d=400, L=3; 40 rows -> 2 680 user-node rows, so the
     bf16x6 training GEMMs (`_x3_ok`), multi-slice `gemm_tn_kernel` launches and the pairwise backward at n=67 all run)."""

@@ -119,6 +119,34 @@ def test_train_step_loss_and_gradients():
         close(v.grad.numpy(), fx["g_" + k], "grad " + k)
 
 
+def test_train_step_with_dropout_live_under_the_kernels_masks():
+    """train_step_dropout.npz: the REFERENCE's autograd with its three nn.Dropout modules drawing the HIP path's counter-hash masks
+    (seed 1001 + site).  The oracle's train mode (the same hook) must reproduce loss and every gradient; the mask generator's
+    restatement is pinned here too (the fixture's values depend on every mask bit)."""
+    fx = load_golden("train_step_dropout.npz")
+    B, K, N, H, C, d, L = (int(v) for v in fx["meta"])
+    ins, w, outs = split_fixture(fx)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.as_params(w).items()}
+    Xn = torch.from_numpy(ins["news_graph_embeddings"]).view(B, K, N, d).clone().requires_grad_(True)
+    ue = torch.from_numpy(ins["user_news_embedding"]).clone().requires_grad_(True)
+    tape = O.SeedTape(float(fx["dropout_rate"]), first=int(fx["first_seed"]))
+    logits = O.training_logits(p, L, ue, torch.from_numpy(ins["user_graph"]), torch.from_numpy(ins["user_category_mask"]),
+                               torch.from_numpy(ins["user_category_indices"]), Xn,
+                               torch.from_numpy(ins["news_graph"]).view(B, K, N, N),
+                               torch.from_numpy(ins["news_graph_mask"]).view(B, K, N), drop=tape)
+    assert tape.next - int(fx["first_seed"]) == int(fx["sites"]) == 3 + 6 * L       # topics, c_n0, c_u0; per layer 2 x (X, alpha) + 2 contexts
+    loss = O.training_loss(logits)
+    loss.backward()
+    close(logits.detach().numpy(), outs["logits"], "logits")
+    close(loss.detach().numpy(), outs["loss"], "loss")
+    close(Xn.grad.view(B * K, N, d).numpy(), fx["g_in_news_graph_embeddings"], "dX_news")
+    close(ue.grad.numpy(), fx["g_in_user_news_embedding"], "dX_user")
+    for k, v in p.items():
+        close(v.grad.numpy(), fx["g_" + k], "grad " + k)
+    keep = O.hash_dropout_keep(1 << 20, 0.2, 7)
+    assert abs(keep.mean() - 0.8) < 2e-3 and not np.array_equal(keep, O.hash_dropout_keep(1 << 20, 0.2, 8))
+
+
 @pytest.mark.parametrize("name", ["devset_tiny.npz", "devset_default.npz", "devset_large.npz", "devset_stress.npz"])
 def test_devset_scores_ranks_metrics(name):
     from digat_amd import synthetic
