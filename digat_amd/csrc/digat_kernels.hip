@@ -186,6 +186,17 @@ __device__ __forceinline__ float leaky02_uniform(float e) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(e), "v"(t));
     return r;
 }
+// Dropout of the training path: a counter-based hash of (seed, flat element index) against floor(p 2^32) — every kernel that applies a
+// dropout (dropout_fwd_kernel and the fused sites: the Eq. 8 scores, the gate, the pooled topics) draws element e's bit from here,
+// so a fused site lands on the elements the stand-alone launch would have (oracle/digat_oracle.py restates it for the tests)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(p * 4294967296.0); }
+__device__ __forceinline__ bool drop_keep(unsigned seed, long e, unsigned thr) {
+    return hash32((unsigned)e * 0x9E3779B9U + hash32(seed + (unsigned)(e >> 32))) >= thr;
+}
 constexpr int TWIN_R = DIGAT_TWIN_R;   // centres with equal adjacency rows served by one wave (user_live_flags_kernel, xattn_sparse_twin_kernel)
 #include "digat_gemm.inc"
 #include "digat_xattn.inc"

@@ -330,3 +330,46 @@ def test_eq8_and_gat_layers_backward_at_the_largest_graphs(n, d):
     got = {"X": Xd2.grad, "W": dv["W"].grad, "bW": dv["bW"].grad, "a1": dv["a1"].grad, "a2": dv["a2"].grad}
     for k in want_g:
         close(got[k], want_g[k].numpy(), f"GAT n={n} grad {k}")
+
+
+@pytest.mark.parametrize("n,d", [(67, 64), (10, 64), (128, 32)])
+def test_eq8_layer_with_attention_dropout_live(n, d, monkeypatch):
+    """digat_xattn_fwd_train / _bwd with the attention dropout LIVE (p = 0.3) against the oracle's autograd under the same keep bits:
+    the dropout is applied inside the score kernels (the tile kernel at 67 and 128 nodes, the small-graph kernel — which also
+    aggregates in place — at 10), forward output and every gradient."""
+    from digat_amd import training
+    from oracle import digat_oracle as O
+    g = torch.Generator().manual_seed(n * 77 + d)
+    B, p_alpha, seed = 3, 0.3, 4242
+    X = torch.randn(B, n, d, generator=g)
+    A = (torch.rand(B, n, n, generator=g) < min(1.0, 6.0 / n))
+    A |= torch.eye(n, dtype=torch.bool).unsqueeze(0)
+    A[1, 0] = False
+    ctx = torch.randn(B, d, generator=g)
+    dOut = torch.randn(B, n, d, generator=g)
+    w = {k: (torch.randn(*shape, generator=g) * scale) for k, shape, scale in
+         [("W", (d, d), d ** -0.5), ("bW", (d,), 0.1), ("F1", (d, d), d ** -0.5), ("F2", (d, d), d ** -0.5), ("F3", (d, d), d ** -0.5),
+          ("b3", (d,), 0.1), ("a", (1, d), d ** -0.5)]}
+    names = {"W": "W.0.weight", "bW": "W.0.bias", "F1": "ffn1.0.weight", "F2": "ffn2.0.weight", "F3": "ffn3.0.weight", "b3": "ffn3.0.bias",
+             "a": "a.0.weight"}
+    p = {"user_graph_attention_" + names[k]: v.clone().requires_grad_(True) for k, v in w.items()}
+    Xo, co = X.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+
+    def drop(x, frac):          # the layer's input arrives already dropped (frac 0.5 site: identity here); alpha: the kernels' bits
+        return x if frac == 0.5 else O.hash_dropout(x.contiguous(), p_alpha, seed)
+
+    want_out = O.cross_graph_attention(p, "user", 0, Xo, A, co, drop=drop)
+    (want_out * dOut).sum().backward()
+    want = {"X": Xo.grad, "ctx": co.grad, **{k: p["user_graph_attention_" + names[k]].grad for k in w}}
+
+    monkeypatch.setattr(training, "_seed", lambda: seed)
+    dv = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
+    Ab = A.to(torch.uint8).to(DEV).contiguous()
+    Xd, cd = X.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
+    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], p_alpha)
+    (out * dOut.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    close(out, want_out.detach().numpy(), f"Eq. 8 n={n} out under dropout", rtol=2e-5, atol=2e-5)
+    got = {"X": Xd.grad, "ctx": cd.grad, **{k: dv[k].grad for k in w}}
+    for k in want:
+        close(got[k], want[k].numpy(), f"Eq. 8 n={n} dropout grad {k}")
