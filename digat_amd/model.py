@@ -72,8 +72,12 @@ class Model(nn.Module):
         user_graph = per_candidate(user_graph)
         user_category_mask = per_candidate(user_category_mask)
         user_category_indices = per_candidate(user_category_indices)
-        candidate_news_embedding = self.news_encoder(news_title_text, news_title_mask)
-        user_news_embedding = per_candidate(self.news_encoder(user_title_text, user_title_mask))
+        if hasattr(self.news_encoder, "encode_pair"):      # a table-backed encoder looks both id lists up at once (one table gradient)
+            candidate_news_embedding, user_news_embedding = self.news_encoder.encode_pair(news_title_text, user_title_text)
+            user_news_embedding = per_candidate(user_news_embedding)
+        else:
+            candidate_news_embedding = self.news_encoder(news_title_text, news_title_mask)
+            user_news_embedding = per_candidate(self.news_encoder(user_title_text, user_title_mask))
         news_rep, user_rep = self.graph_encoder(candidate_news_embedding, news_graph, news_graph_mask,
                                                 user_news_embedding, user_graph, user_category_mask,
                                                 user_category_indices)
@@ -128,6 +132,20 @@ class PrecomputedNewsEncoder(nn.Module):
     @property
     def table(self):
         return self.embed_table
+
+    @staticmethod
+    def _ids(news_ids):
+        return news_ids.squeeze(-1) if news_ids.dim() >= 3 and news_ids.shape[-1] == 1 else news_ids
+
+    def encode_pair(self, candidate_ids, history_ids):
+        """Model.forward's two lookups (model.py:72-73) in one autograd node: on the GPU with a trainable table the gradient of both is
+        ONE dense table gradient from one launch (training.TableLookup2); otherwise two plain lookups."""
+        a, b = self._ids(candidate_ids), self._ids(history_ids)
+        if self.embed_table.requires_grad and torch.is_grad_enabled() and self.embed_table.is_cuda and self.embed_table.shape[1] % 4 == 0 \
+                and self.embed_table.shape[1] <= 1024 and self.embed_table.dtype == torch.float32:
+            from .training import TableLookup2
+            return TableLookup2.apply(self.embed_table, a, b)
+        return self.forward(a), self.forward(b)
 
     def forward(self, news_ids, _mask=None):
         if news_ids.dim() == 3 and news_ids.shape[2] == 1:

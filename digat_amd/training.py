@@ -171,6 +171,37 @@ class Dropout(Function):
         return dx, None
 
 
+class TableLookup2(Function):
+    """Rows of ONE embedding table for two id lists — the candidate graphs' nodes and the histories of a training batch
+    (model.py:72-73 through a table-backed news encoder) — with ONE dense table gradient from one launch
+    (``digat_embedding_bwd_unsorted``: equal ids added in a fixed order, no sort, no atomics, two launches), where
+    ``F.embedding``'s backward sorts, scans and scatters per lookup (18 launches each at these sizes) and autograd then adds the
+    two 104 MB gradients."""
+
+    @staticmethod
+    def forward(ctx, table, ids_a, ids_b):
+        ids_a, ids_b = ids_a.long().contiguous(), ids_b.long().contiguous()
+        ctx.save_for_backward(ids_a, ids_b)
+        ctx.table_shape = tuple(table.shape)
+        return torch.nn.functional.embedding(ids_a, table), torch.nn.functional.embedding(ids_b, table)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ids_a, ids_b = ctx.saved_tensors
+        V, dm = ctx.table_shape
+        dev = ids_a.device
+        dtable = torch.zeros((V, dm), dtype=torch.float32, device=dev)
+        ga = _f(ga) if ga is not None else None
+        gb = _f(gb) if gb is not None else None
+        Ma, Mb = (ids_a.numel() if ga is not None else 0), (ids_b.numel() if gb is not None else 0)
+        nb = L().digat_embedding_bwd_unsorted_workspace_bytes(Ma + Mb, dm)
+        ws = _lib.workspace(nb, dev, "embedding_bwd")
+        _lib.check(L().digat_embedding_bwd_unsorted(ids_a.data_ptr() if Ma else None, _lib.ptr(ga), dm, Ma, ids_b.data_ptr() if Mb else None,
+                                                    _lib.ptr(gb), dm, Mb, dm, V, dtable.data_ptr(), ws.data_ptr(), nb, S()),
+                   "digat_embedding_bwd_unsorted")
+        return dtable, None, None
+
+
 def dropout(x, p, training=True):
     return Dropout.apply(x, p) if (training and p > 0) else x
 

@@ -373,3 +373,42 @@ def test_eq8_layer_with_attention_dropout_live(n, d, monkeypatch):
     got = {"X": Xd.grad, "ctx": cd.grad, **{k: dv[k].grad for k in w}}
     for k in want:
         close(got[k], want[k].numpy(), f"Eq. 8 n={n} dropout grad {k}")
+
+
+def test_table_lookup_of_two_id_lists_has_one_dense_gradient_equal_to_two_embedding_backwards():
+    """training.TableLookup2 (the table-backed news encoder's two lookups of a training batch, one launch for the table gradient)
+    against torch's own embedding backward: many repeated ids (a history repeats news, candidates share neighbours), ids only one
+    list holds, rows nobody looks up (zero gradient), a row stride that is not 64 floats; twice: bit-reproducible."""
+    from digat_amd import training
+    from digat_amd.model import PrecomputedNewsEncoder
+    g = torch.Generator().manual_seed(5)
+    V, dm = 5000, 400
+    table = torch.randn(V, dm, generator=g)
+    ids_a = torch.randint(0, 300, (320, 10), generator=g)          # heavy repetition
+    ids_b = torch.randint(100, V, (64, 50), generator=g)
+    ids_b[:, :5] = 7                                               # one id 320 times in the second list, absent from the first
+    wa, wb = torch.randn(320, 10, dm, generator=g), torch.randn(64, 50, dm, generator=g)
+    t0 = table.clone().requires_grad_(True)
+    ((torch.nn.functional.embedding(ids_a, t0) * wa).sum() + (torch.nn.functional.embedding(ids_b, t0) * wb).sum()).backward()
+    grads = []
+    for _ in range(2):
+        t1 = table.to(DEV).requires_grad_(True)
+        a, b = training.TableLookup2.apply(t1, ids_a.to(DEV), ids_b.to(DEV))
+        assert torch.equal(a.cpu(), table[ids_a]) and torch.equal(b.cpu(), table[ids_b])
+        ((a * wa.to(DEV)).sum() + (b * wb.to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        grads.append(t1.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    close(grads[0], t0.grad.numpy(), "table gradient", rtol=1e-5, atol=1e-6)      # sums of up to 320 rows in another order
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[ids_a.flatten()] = False
+    untouched[ids_b.flatten()] = False
+    assert untouched.any() and float(grads[0].cpu()[untouched].abs().max()) == 0.0
+    # through the encoder stand-in, as Model.forward calls it ([.., 1] "titles" of one token), and only one output used
+    enc = PrecomputedNewsEncoder(table, trainable=True).to(DEV)
+    ca, hb = enc.encode_pair(ids_a.to(DEV).unsqueeze(-1), ids_b.to(DEV).unsqueeze(-1))
+    assert ca.shape == (320, 10, dm) and hb.shape == (64, 50, dm)
+    (hb * wb.to(DEV)).sum().backward()
+    t2 = table.clone().requires_grad_(True)
+    (torch.nn.functional.embedding(ids_b, t2) * wb).sum().backward()
+    close(enc.embed_table.grad, t2.grad.numpy(), "table gradient, second list only", rtol=1e-5, atol=1e-6)
