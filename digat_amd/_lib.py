@@ -107,7 +107,7 @@ _SIGNATURES = {
     "digat_msa_row_grad_ld": (C.c_int64, [C.c_int] * 3),
     "digat_embedding_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "digat_embedding_bwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_int, _f, _f, C.c_size_t, _f]),
-    "digat_embedding_bwd_unsorted_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "digat_embedding_bwd_unsorted_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int64]),
     "digat_embedding_bwd_unsorted": (C.c_int, [_f, _f, C.c_int64, C.c_int64, _f, _f, C.c_int64, C.c_int64, C.c_int, C.c_int64, _f, _f, C.c_size_t,
                                                _f]),
     "digat_encoder_grouped_workspace_bytes": (C.c_size_t, [C.c_int] * 6),

@@ -174,7 +174,7 @@ class Dropout(Function):
 class TableLookup2(Function):
     """Rows of ONE embedding table for two id lists — the candidate graphs' nodes and the histories of a training batch
     (model.py:72-73 through a table-backed news encoder) — with ONE dense table gradient from one launch
-    (``digat_embedding_bwd_unsorted``: equal ids added in a fixed order, no sort, no atomics, two launches), where
+    (``digat_embedding_bwd_unsorted``: equal ids added in a fixed order, no sort, two launches), where
     ``F.embedding``'s backward sorts, scans and scatters per lookup (18 launches each at these sizes) and autograd then adds the
     two 104 MB gradients."""
 
@@ -194,7 +194,7 @@ class TableLookup2(Function):
         ga = _f(ga) if ga is not None else None
         gb = _f(gb) if gb is not None else None
         Ma, Mb = (ids_a.numel() if ga is not None else 0), (ids_b.numel() if gb is not None else 0)
-        nb = L().digat_embedding_bwd_unsorted_workspace_bytes(Ma + Mb, dm)
+        nb = L().digat_embedding_bwd_unsorted_workspace_bytes(Ma + Mb, dm, V)
         ws = _lib.workspace(nb, dev, "embedding_bwd")
         _lib.check(L().digat_embedding_bwd_unsorted(ids_a.data_ptr() if Ma else None, _lib.ptr(ga), dm, Ma, ids_b.data_ptr() if Mb else None,
                                                     _lib.ptr(gb), dm, Mb, dm, V, dtable.data_ptr(), ws.data_ptr(), nb, S()),

@@ -557,10 +557,11 @@ int digat_embedding_bwd(const float* row_grad, int64_t ld_row_grad, const int32_
 /* The same sum for a few thousand looked-up rows without a sorted order (the backward of torch.nn.functional.embedding on a wide
  * table, trainer.py:98-102 through the news encoder's table): ids0 [M0] / ids1 [M1] int64 (two lookups of ONE table; ids1 may be NULL
  * with M1 = 0), their row gradients g0 / g1 (row strides ld0 / ld1); table_grad [V, dm] zero-filled by the caller; an id outside
- * [0, V) receives nothing.  Two launches: per chunk of 64 positions the first position of an id adds the chunk's rows of that id in
- * ascending order, then the first position overall adds those partial rows in ascending chunk order — bit-reproducible, no atomics.
+ * [0, V) receives nothing.  Two launches (and a memset of 8 V bytes): per chunk of 64 positions the first position of an id adds the
+ * chunk's rows of that id in ascending order, then the first position overall adds those partial rows in ascending chunk order —
+ * bit-reproducible (the only atomics are an integer min and an integer count per id).
  * dm % 4 == 0, dm <= 1024, M0 + M1 <= 2^24 (the id scans are quadratic in M: meant for M of a few thousand). */
-size_t digat_embedding_bwd_unsorted_workspace_bytes(int64_t M, int dm);
+size_t digat_embedding_bwd_unsorted_workspace_bytes(int64_t M, int dm, int64_t V);
 int digat_embedding_bwd_unsorted(const int64_t* ids0, const float* g0, int64_t ld0, int64_t M0, const int64_t* ids1, const float* g1,
                                  int64_t ld1, int64_t M1, int dm, int64_t V, float* table_grad, void* workspace, size_t workspace_bytes,
                                  void* stream);
