@@ -38,6 +38,12 @@ class MsaParams(C.Structure):
                                              "qkv_wsplit", "a1_wsplit")])
 
 
+class SplitJob(C.Structure):
+    """digat_split_job (include/digat_hip.h)."""
+    _fields_ = [("w0", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("layout", C.c_int32),
+                ("reserved", C.c_int32), ("image", C.c_void_p)]
+
+
 class GatherJob(C.Structure):
     """digat_gather_job (include/digat_hip.h)."""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("rows", C.c_int64),
@@ -148,16 +154,18 @@ _SIGNATURES = {
     "digat_sum_nodes": (C.c_int, [_f, _f, C.c_int, C.c_int, C.c_int, _f]),
     "digat_xattn_train_save_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_xattn_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
-    "digat_xattn_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
-    "digat_xattn_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f]),
+    "digat_xattn_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f]),
+    "digat_xattn_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f, _f]),
+    "digat_split_job_bytes": (C.c_size_t, [C.c_int] * 4),
+    "digat_split_jobs": (C.c_int, [C.POINTER(SplitJob), C.c_int, _f]),
     "digat_news_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_fwd_train": (C.c_int, [_f] * 8 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
     "digat_news_ctx_bwd": (C.c_int, [_f] * 6 + [C.c_float, _f, C.c_size_t] + [_f] * 6 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_user_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 5),
     "digat_user_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
-    "digat_user_ctx_fwd_train": (C.c_int, [_f] * 13 + [C.c_float, C.c_uint32] + [C.c_int] * 5 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
-    "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 6 + [_f, C.c_size_t, _f]),
+    "digat_user_ctx_fwd_train": (C.c_int, [_f] * 13 + [C.c_float, C.c_uint32] + [C.c_int] * 5 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f]),
+    "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 6 + [_f, C.c_size_t, _f, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "digat_profile_set_kinds": (C.c_int, [C.c_uint]),
@@ -174,7 +182,7 @@ _LAB_SIGNATURES = {"digat_set_staged_xattn": (C.c_int, [C.c_int])}
 KERNEL_KINDS = ("proj", "linear", "xattn", "pool", "topic", "glue", "agg")
 XATTN_PARTS = ("twin", "l0", "news", "other")      # digat_profile_xattn_parts: the Eq. 8 launches by kernel
 EXPORTED = tuple(_SIGNATURES)
-ABI_VERSION = 3          # include/digat_hip.h: DIGAT_ABI_VERSION the signature table above was written for
+ABI_VERSION = 4          # include/digat_hip.h: DIGAT_ABI_VERSION the signature table above was written for
 
 
 def lib() -> C.CDLL:

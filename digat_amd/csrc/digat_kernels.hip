@@ -374,16 +374,57 @@ size_t digat_split_weights_bytes(int rows, int K) {
     return (size_t)((rows + 79) / 80) * ((K + 31) / 32) * WS_SLOTS * 16;       // one 15 KB image per (80-row strip, K tile)
 }
 
+// A training entry that was handed a ready-made image of its weights (digat_split_jobs: every image of a step in one launch) passes
+// the image where its helpers expect their split destination and names it here: the split launch for exactly that pointer is skipped.
+static thread_local const void* tl_premade_image = nullptr;
+struct PremadeImage {
+    const void* prev;
+    explicit PremadeImage(const void* image) : prev(tl_premade_image) { tl_premade_image = image; }
+    ~PremadeImage() { tl_premade_image = prev; }
+};
 // format: DIGAT_GEMM_BF16X6 (three bf16 pieces; what every training entry uses) or DIGAT_GEMM_F16X3 (two scaled fp16 pieces)
 static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st,
                         int transposed = 0, int format = 0) {
     if (format != 0 && format != 1) return DIGAT_ERR_ARG;
+    if (wsplit && wsplit == tl_premade_image) return format == 0 ? DIGAT_OK : DIGAT_ERR_ARG;
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     wsplit_note(wsplit, format);
     hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(blocks), dim3(256), 0, st, w0, w1, w2, nseg, nsegs, K, (unsigned short*)wsplit, transposed,
                        format == 1 ? 2 : 3);
+    DIGAT_CHECK_LAUNCH();
+    return DIGAT_OK;
+}
+
+// every split image of a training step in ONE launch (blockIdx.y = job): 20 split launches per 64 x 5-row step before
+size_t digat_split_job_bytes(int rows, int cols, int layout, int matrices) {
+    if (rows <= 0 || cols <= 0 || (matrices != 1 && matrices != 3)) return 0;
+    if (layout == 0) return digat_split_weights_bytes(rows * matrices, cols);
+    if (layout == 1) return matrices == 1 ? digat_split_weights_bytes(cols, rows) : digat_split_weights_bytes(cols, 3 * rows);
+    return 0;
+}
+int digat_split_jobs(const digat_split_job* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 0 || njobs > SPLIT_MAX_JOBS) return DIGAT_ERR_ARG;
+    if (njobs == 0) return DIGAT_OK;
+    SplitJobsDev all;
+    memset(&all, 0, sizeof(all));
+    long most = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const digat_split_job& j = jobs[k];
+        const bool three = j.w1 != nullptr || j.w2 != nullptr;
+        if (!j.w0 || !j.image || j.rows <= 0 || j.cols <= 0 || (three && (!j.w1 || !j.w2)) || (j.layout != 0 && j.layout != 1)) return DIGAT_ERR_ARG;
+        SplitJobDev& o = all.j[k];
+        o.w0 = j.w0; o.w1 = three ? j.w1 : j.w0; o.w2 = three ? j.w2 : j.w0; o.out = (unsigned short*)j.image;
+        if (j.layout == 0) { o.nseg = j.rows; o.nsegs = three ? 3 : 1; o.K = j.cols; o.transposed = 0; }
+        else { o.nseg = j.cols; o.nsegs = 1; o.K = three ? 3 * j.rows : j.rows; o.transposed = three ? 2 : 1; }
+        const long total = (long)o.nseg * o.nsegs * o.K;
+        if (total > most) most = total;
+        wsplit_note(j.image, 0);
+    }
+    long bx = (most + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(split_weights_jobs_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, all);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
 }

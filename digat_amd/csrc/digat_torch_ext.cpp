@@ -161,10 +161,18 @@ at::Tensor scratch(const at::Tensor& like, size_t bytes) {       // stream-order
 }
 at::Tensor byte_buffer(const at::Tensor& like, size_t bytes) { return at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte)); }
 float* out_f32(at::Tensor& t) { return t.data_ptr<float>(); }
+// a ready-made split image (digat_split_jobs), or nothing: a byte tensor on the inputs' device, at least `bytes` long
+const void* image_of(const c10::optional<at::Tensor>& image, const at::Tensor& like, size_t bytes) {
+    if (!image.has_value()) return nullptr;
+    need(image->is_cuda() && image->device() == like.device() && image->scalar_type() == at::kByte && image->is_contiguous() &&
+         (size_t)image->numel() >= bytes, "image: a contiguous uint8 tensor on the inputs' device holding the whole split image");
+    return image->data_ptr();
+}
 
 std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec, const at::Tensor& W,
                                                    const at::Tensor& bW, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3,
-                                                   const at::Tensor& b3, const at::Tensor& a, double p, int64_t seed) {
+                                                   const at::Tensor& b3, const at::Tensor& a, double p, int64_t seed,
+                                                   const c10::optional<at::Tensor>& image) {
     need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
     const c10::DeviceGuard guard(Xd.device());          // allocations and the launch on the input's device, whatever the current one is
@@ -175,14 +183,15 @@ std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const a
     at::Tensor save = byte_buffer(Xd, nsave), ws = scratch(Xd, nws);
     check(digat_xattn_fwd_train(f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"), f32(bW, Xd, "bW"), f32(F1, Xd, "F1"),
                                 f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(b3, Xd, "b3"), f32(a, Xd, "a"), out_f32(out), (float)p, (uint32_t)seed, B, n, d,
-                                save.data_ptr(), nsave, ws.data_ptr(), nws, stream_of(Xd)), "digat_xattn_fwd_train");
+                                save.data_ptr(), nsave, ws.data_ptr(), nws, image_of(image, Xd, digat_split_job_bytes(d, d, 0, 3)), stream_of(Xd)),
+          "digat_xattn_fwd_train");
     return {out, save};
 }
 
 // -> dX, dctx, dW3 ([3,d,d]: dW, dF1, dF2 written in place as one product), dbW, dF3, db3, da
 std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out, const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec,
                                   const at::Tensor& W, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3, const at::Tensor& a, double p,
-                                  const at::Tensor& save) {
+                                  const at::Tensor& save, const c10::optional<at::Tensor>& image) {
     need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
     const c10::DeviceGuard guard(Xd.device());
@@ -199,7 +208,7 @@ std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out,
     check(digat_xattn_bwd(f32(dOut, Xd, "dOut"), f32(out, Xd, "out"), f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"),
                           f32(F1, Xd, "F1"), f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(a, Xd, "a"), (float)p, save.data_ptr(), nsave, out_f32(dX),
                           out_f32(dc), w3, out_f32(dbW), w3 + dd, w3 + 2 * dd, out_f32(dF3), out_f32(db3), out_f32(da), B, n, d, ws.data_ptr(), nws,
-                          stream_of(Xd)), "digat_xattn_bwd");
+                          image_of(image, Xd, digat_split_job_bytes(d, d, 1, 3)), stream_of(Xd)), "digat_xattn_bwd");
     return {dX, dc, dW3, dbW, dF3, db3, da};
 }
 
@@ -241,7 +250,7 @@ at::Tensor news_ctx_bwd(const at::Tensor& dout, const at::Tensor& X, const at::T
 std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, const at::Tensor& cat_mask, const at::Tensor& cat_idx, const at::Tensor& c_n,
                                                       const at::Tensor& Ku, const at::Tensor& Qu, const at::Tensor& bQu, const at::Tensor& Fa,
                                                       const at::Tensor& bFa, const at::Tensor& Kua, const at::Tensor& Qua, const at::Tensor& bQua,
-                                                      int64_t H, int64_t C1, double p, int64_t seed) {
+                                                      int64_t H, int64_t C1, double p, int64_t seed, const c10::optional<at::Tensor>& image) {
     need(Xu.dim() == 3, "Xu [B,U,d] expected");
     const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
     const c10::DeviceGuard guard(Xu.device());
@@ -255,7 +264,7 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, cons
     check(digat_user_ctx_fwd_train(f32(Xu, Xu, "Xu"), bytes(cat_mask, Xu, "cat_mask"), i64(cat_idx, Xu, "cat_idx"), f32(c_n, Xu, "c_n"), f32(Ku, Xu, "Ku"),
                                    f32(Qu, Xu, "Qu"), f32(bQu, Xu, "bQu"), f32(Fa, Xu, "Fa"), f32(bFa, Xu, "bFa"), f32(Kua, Xu, "Kua"), f32(Qua, Xu, "Qua"),
                                    f32(bQua, Xu, "bQua"), out_f32(out), (float)p, (uint32_t)seed, B, U, (int)H, (int)C1, d, save.data_ptr(), nsave,
-                                   ws.data_ptr(), nws, stream_of(Xu)), "digat_user_ctx_fwd_train");
+                                   ws.data_ptr(), nws, image_of(image, Xu, digat_split_job_bytes(d, d, 0, 1)), stream_of(Xu)), "digat_user_ctx_fwd_train");
     return {out, save};
 }
 
@@ -263,7 +272,8 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, cons
 std::tuple<at::Tensor, at::Tensor> user_ctx_bwd(const at::Tensor& dout, const at::Tensor& Xu, const at::Tensor& cat_mask, const at::Tensor& cat_idx,
                                                 const at::Tensor& c_n, const at::Tensor& Ku, const at::Tensor& Qu, const at::Tensor& Fa,
                                                 const at::Tensor& Kua, const at::Tensor& Qua, double p, const at::Tensor& save,
-                                                std::vector<at::Tensor> grads, bool accumulate, int64_t H, int64_t C1) {
+                                                std::vector<at::Tensor> grads, bool accumulate, int64_t H, int64_t C1,
+                                                const c10::optional<at::Tensor>& image) {
     need(grads.size() == 8, "eight parameter-gradient tensors expected");
     need(Xu.dim() == 3, "Xu [B,U,d] expected");
     const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
@@ -282,7 +292,7 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_bwd(const at::Tensor& dout, const at
                              f32(Ku, Xu, "Ku"), f32(Qu, Xu, "Qu"), f32(Fa, Xu, "Fa"), f32(Kua, Xu, "Kua"), f32(Qua, Xu, "Qua"), (float)p, save.data_ptr(), nsave,
                              out_f32(dXu), out_f32(dc), out_f32(grads[0]), out_f32(grads[1]), out_f32(grads[5]), out_f32(grads[2]), out_f32(grads[6]),
                              out_f32(grads[3]), out_f32(grads[4]), out_f32(grads[7]), B, U, (int)H, (int)C1, d, accumulate ? 1 : 0, ws.data_ptr(), nws,
-                             stream_of(Xu)), "digat_user_ctx_bwd");
+                             image_of(image, Xu, digat_split_job_bytes(d, d, 1, 1)), stream_of(Xu)), "digat_user_ctx_bwd");
     return {dXu, dc};
 }
 

@@ -380,14 +380,16 @@ class XattnFused(Function):
     relu'(K3+K1+K2)), the three projection backwards, K3's — in ``digat_xattn_bwd``."""
 
     @staticmethod
-    def forward(ctx, Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p_alpha):
+    def forward(ctx, Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p_alpha, images=None):
+        """``images``: None, or (forward image, backward image) of (W, F1, F2) from ``split_images`` (either may be None)."""
         Xd, cvec = _f(Xd), _f(cvec)
         B, n, d = Xd.shape
         dev = Xd.device
         p = float(p_alpha)
+        img_f, ctx.img_b = images if images is not None else (None, None)
         E = _lib.ext()
         if E is not None:          # the thin torch extension: tensors in, out / save allocated there (the same C entry)
-            out, save = E.xattn_fwd_train(Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p, _seed() if p > 0 else 0)
+            out, save = E.xattn_fwd_train(Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p, _seed() if p > 0 else 0, img_f)
             ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
             ctx.p, ctx.sizes = p, None
             return out
@@ -396,7 +398,7 @@ class XattnFused(Function):
         save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
         _lib.check(L().digat_xattn_fwd_train(Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
                                              F2.data_ptr(), F3.data_ptr(), b3.data_ptr(), a.data_ptr(), out.data_ptr(), p,
-                                             _seed() if p > 0 else 0, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, S()),
+                                             _seed() if p > 0 else 0, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), S()),
                    "digat_xattn_fwd_train")
         ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
         ctx.p, ctx.sizes = p, (nsave, nws)
@@ -410,8 +412,8 @@ class XattnFused(Function):
         dOut = _f(dOut)
         E = _lib.ext()
         if E is not None and ctx.sizes is None:
-            dX, dc, dW3, dbW, dF3, db3, da = E.xattn_bwd(dOut, out, Xd, A, cvec, W, F1, F2, F3, a, ctx.p, save)
-            return dX, None, dc, dW3[0], dbW, dW3[1], dW3[2], dF3, db3, da.view_as(a), None
+            dX, dc, dW3, dbW, dF3, db3, da = E.xattn_bwd(dOut, out, Xd, A, cvec, W, F1, F2, F3, a, ctx.p, save, ctx.img_b)
+            return dX, None, dc, dW3[0], dbW, dW3[1], dW3[2], dF3, db3, da.view_as(a), None, None
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX, dc = torch.empty_like(Xd), torch.empty_like(cvec)
@@ -423,9 +425,9 @@ class XattnFused(Function):
         _lib.check(L().digat_xattn_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(),
                                        F1.data_ptr(), F2.data_ptr(), F3.data_ptr(), a.data_ptr(), ctx.p, save.data_ptr(), nsave,
                                        dX.data_ptr(), dc.data_ptr(), dW.data_ptr(), dbW.data_ptr(), dF1.data_ptr(), dF2.data_ptr(),
-                                       dF3.data_ptr(), db3.data_ptr(), da.data_ptr(), B, n, d, ws.data_ptr(), nws, S()),
+                                       dF3.data_ptr(), db3.data_ptr(), da.data_ptr(), B, n, d, ws.data_ptr(), nws, _lib.ptr(ctx.img_b), S()),
                    "digat_xattn_bwd")
-        return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None
+        return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None, None
 
 
 class GatFused(Function):
@@ -582,9 +584,11 @@ class UserCtxFused(Function):
     """compute_user_graph_context (graphEncoders.py:123-134), training mode."""
 
     @staticmethod
-    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic, sink=None):
+    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic, sink=None, images=None):
+        """``images``: None, or (forward image, backward image) of featureAffine.weight from ``split_images``."""
         Xu, c_n = _f(Xu), _f(c_n)
         ctx.sink = sink
+        img_f, ctx.img_b = images if images is not None else (None, None)
         if sink is not None:
             sink.enter("user_ctx")
         B, U, d = Xu.shape
@@ -593,7 +597,7 @@ class UserCtxFused(Function):
         if E is not None:
             p = float(p_topic)
             out, save = E.user_ctx_fwd_train(Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, int(H), int(C1), p,
-                                             _seed() if p > 0 else 0)
+                                             _seed() if p > 0 else 0, img_f)
             ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
             ctx.p, ctx.sizes, ctx.dims = p, None, (H, C1)
             return out
@@ -605,7 +609,7 @@ class UserCtxFused(Function):
         _lib.check(L().digat_user_ctx_fwd_train(Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(), Ku.data_ptr(),
                                                 Qu.data_ptr(), bQu.data_ptr(), Fa.data_ptr(), bFa.data_ptr(), Kua.data_ptr(),
                                                 Qua.data_ptr(), bQua.data_ptr(), out.data_ptr(), p, _seed() if p > 0 else 0,
-                                                B, U, H, C1, d, save.data_ptr(), nsave, ws.data_ptr(), nws, S()),
+                                                B, U, H, C1, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), S()),
                    "digat_user_ctx_fwd_train")
         ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
         ctx.p, ctx.sizes, ctx.dims = p, (nsave, nws), (H, C1)
@@ -626,10 +630,11 @@ class UserCtxFused(Function):
         dKu, dQu, dFa, dKua, dQua, dbQu, dbFa, dbQua = grads
         E = _lib.ext()
         if E is not None and ctx.sizes is None:
-            dXu, dc = E.user_ctx_bwd(dout, Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, ctx.p, save, list(grads), bool(acc), int(H), int(C1))
+            dXu, dc = E.user_ctx_bwd(dout, Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, ctx.p, save, list(grads), bool(acc), int(H), int(C1),
+                                     ctx.img_b)
             if sink is not None and not sink.end("user_ctx"):
-                return (dXu, None, None, dc) + (None,) * 12
-            return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None
+                return (dXu, None, None, dc) + (None,) * 13
+            return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
@@ -637,35 +642,82 @@ class UserCtxFused(Function):
                                           Ku.data_ptr(), Qu.data_ptr(), Fa.data_ptr(), Kua.data_ptr(), Qua.data_ptr(), ctx.p,
                                           save.data_ptr(), nsave, dXu.data_ptr(), dc.data_ptr(), dKu.data_ptr(), dQu.data_ptr(),
                                           dbQu.data_ptr(), dFa.data_ptr(), dbFa.data_ptr(), dKua.data_ptr(), dQua.data_ptr(),
-                                          dbQua.data_ptr(), B, U, H, C1, d, acc, ws.data_ptr(), nws, S()), "digat_user_ctx_bwd")
+                                          dbQua.data_ptr(), B, U, H, C1, d, acc, ws.data_ptr(), nws, _lib.ptr(ctx.img_b), S()), "digat_user_ctx_bwd")
         if sink is not None and not sink.end("user_ctx"):
-            return (dXu, None, None, dc) + (None,) * 12
-        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None
+            return (dXu, None, None, dc) + (None,) * 13
+        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
 # the reference's four functions, training mode
 # --------------------------------------------------------------------------------------------------
+def split_images(jobs, dev):
+    """Every split image of a step's matrix-core weights in ONE launch (``digat_split_jobs``).  ``jobs``: a list of
+    ((w0, w1, w2) or (w0,), layout) with nn.Linear weights [rows, cols]; returns one uint8 view per job, in order (all views of one
+    buffer: kept alive by whoever holds a view)."""
+    L_ = L()
+    sizes = []
+    for ws, layout in jobs:
+        rows, cols = ws[0].shape
+        sizes.append((L_.digat_split_job_bytes(rows, cols, layout, len(ws)) + 255) // 256 * 256)
+    buf = torch.empty(max(sum(sizes), 256), dtype=torch.uint8, device=dev)
+    arr = (_lib.SplitJob * len(jobs))()
+    views, off = [], 0
+    for k, ((ws, layout), nb) in enumerate(zip(jobs, sizes)):
+        rows, cols = ws[0].shape
+        view = buf[off:off + nb]
+        arr[k] = _lib.SplitJob(ws[0].data_ptr(), ws[1].data_ptr() if len(ws) == 3 else None, ws[2].data_ptr() if len(ws) == 3 else None,
+                               rows, cols, layout, 0, view.data_ptr())
+        views.append(view)
+        off += nb
+    _lib.check(L_.digat_split_jobs(arr, len(jobs), S()), "digat_split_jobs")
+    return views
+
+
+def step_images(enc, rows_news, rows_user, rows_topics, dev):
+    """The split images of one training forward + backward of ``enc`` (the Eq. 8 projections of every layer and graph, featureAffine),
+    for the products that run on the bf16x6 kernel at these row counts: {(graph, layer): (fwd, bwd)}, {"fa": (fwd, bwd)}."""
+    d = enc.news_embedding_dim
+    jobs, keys = [], []
+    for g, rows in (("news", rows_news), ("user", rows_user)):
+        if not (_x3_ok(rows, d, d) and g in getattr(enc, "EQ8", ("news", "user"))):
+            continue
+        for i in range(enc.graph_depth):
+            ws = tuple(getattr(enc, f"{g}_graph_attention_{nm}")[i].weight for nm in ("W", "ffn1", "ffn2"))
+            jobs += [(ws, 0), (ws, 1)]
+            keys += [(g, i, 0), (g, i, 1)]
+    if _x3_ok(rows_topics, d, d):
+        jobs += [((enc.featureAffine.weight,), 0), ((enc.featureAffine.weight,), 1)]
+        keys += [("fa", 0, 0), ("fa", 0, 1)]
+    if not jobs or len(jobs) > 24:
+        return {}
+    views = dict(zip(keys, split_images(jobs, dev)))
+    out = {}
+    for (g, i, _), _v in views.items():
+        out[(g, i)] = (views[(g, i, 0)], views[(g, i, 1)])
+    return out
+
+
 def news_graph_context(enc, X, mask_bytes, p, training=True, sink=None):
     ca, g = enc.candidate_attention, enc.news_graph_W
     return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0, sink)
 
 
-def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True, sink=None):
+def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True, sink=None, images=None):
     ua, fa = enc.userAttention, enc.featureAffine
     return UserCtxFused.apply(Xu, cat_mask_bytes, cat_idx, c_n, enc.user_news_K.weight, enc.user_news_Q.weight, enc.user_news_Q.bias,
                               fa.weight, fa.bias, ua.K.weight, ua.Q.weight, ua.Q.bias, enc.max_history_num, enc.category_num,
-                              p if training else 0.0, sink)
+                              p if training else 0.0, sink, images)
 
 
-def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True):
+def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True, images=None):
     Xd = dropout(X, p / 2, training)
     F3 = getattr(enc, f"{g}_graph_attention_ffn3")[i]
     W = getattr(enc, f"{g}_graph_attention_W")[i]
     return XattnFused.apply(Xd, A_bytes, ctx_vec, W.weight, W.bias,
                             getattr(enc, f"{g}_graph_attention_ffn1")[i].weight,
                             getattr(enc, f"{g}_graph_attention_ffn2")[i].weight, F3.weight, F3.bias,
-                            getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0)
+                            getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0, images)
 
 
 def gat_embeddings(enc, g, i, X, A_bytes, p, training=True):
@@ -728,12 +780,17 @@ def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask,
     p, Xn, An, Mn, Xu, Au, cm, ci = _train_inputs(enc, news_graph_embeddings, news_graph, news_graph_mask, user_news_embedding,
                                                   user_graph, user_category_mask, user_category_indices)
     sink = StepSink() if getattr(enc, "sum_shared_gradients_in_library", True) else None
+    # every split image the step's matrix-core products read — forward and backward, each layer and graph, featureAffine — in ONE
+    # launch now (round 6: each call split its own before, 20 launches per step); the weights do not change before the backward
+    img = step_images(enc, Xn.shape[0] * Xn.shape[1], Xu.shape[0] * Xu.shape[1], Xu.shape[0] * enc.category_num, Xn.device) \
+        if getattr(enc, "split_weights_once_per_step", True) else {}
+    fa = img.get(("fa", 0))
     c_n = news_graph_context(enc, Xn, Mn, p, sink=sink)
-    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink)
+    c_u = user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink, images=fa)
     for i in range(enc.graph_depth):
-        Xn_next = graph_embeddings(enc, "news", i, Xn, An, c_u, p)
-        Xu_next = graph_embeddings(enc, "user", i, Xu, Au, c_n, p)
+        Xn_next = graph_embeddings(enc, "news", i, Xn, An, c_u, p, images=img.get(("news", i)))
+        Xu_next = graph_embeddings(enc, "user", i, Xu, Au, c_n, p, images=img.get(("user", i)))
         Xn, Xu = Xn_next, Xu_next
         c_n = c_n + news_graph_context(enc, Xn, Mn, p, sink=sink)
-        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink)
+        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink, images=fa)
     return c_n, c_u

@@ -37,9 +37,11 @@
 extern "C" {
 #endif
 
-/* 3 (round 6; 2 was this round's first bump): digat_params grew featureAffine_fsplit; digat_news_ctx_bwd / digat_user_ctx_bwd took `accumulate_params` in round 5 and entry points were added without a
- * bump: a loader built for one version must refuse a library of another (digat_amd/_lib.py does) rather than shift arguments. */
-#define DIGAT_ABI_VERSION 3
+/* 4 (round 6): digat_xattn_fwd_train / digat_xattn_bwd / digat_user_ctx_fwd_train / digat_user_ctx_bwd take a ready-made split image
+ * (or NULL) before `stream`.  3: digat_params grew featureAffine_fsplit; digat_news_ctx_bwd / digat_user_ctx_bwd took
+ * `accumulate_params` in round 5 and entry points were added without a bump: a loader built for one version must refuse a library
+ * of another (digat_amd/_lib.py does) rather than shift arguments. */
+#define DIGAT_ABI_VERSION 4
 #define DIGAT_MAX_NODES 128
 #define DIGAT_MAX_DEPTH 16
 
@@ -417,16 +419,34 @@ enum { DIGAT_GEMM_BF16X6 = 0, DIGAT_GEMM_F16X3 = 1 };
  *
  * a1 / a2 (graphEncoders.py:143-154, :163-174).  X is the layer input AFTER its input dropout drop_{p/2} (the residual uses
  * the dropped input); out = relu(drop_p(alpha) h) + X.  The backward recomputes relu'(K3+K1+K2) from the saved projections. */
+/* Split images made ahead (round 6).  The matrix-core products of these entries read their weights as bf16x6 images; by default
+ * every call splits its own (the weights change every optimiser step): 20 split launches per 64 x 5-row step.  digat_split_jobs
+ * writes any number of images (<= 24) in ONE launch — once per step, after the optimiser's update — and the entries take the
+ * image of THEIR weights in THEIR layout through the *_image arguments (NULL: split inside, as before).  An image is only a
+ * function of the weight values: the caller keeps it valid (same weights, not freed) until the calls that read it have been
+ * enqueued on the same stream.
+ *   layout 0: y = x [w0 | w1 | w2]^T, the forward product of nn.Linear weights [rows, cols] (w1 = w2 = NULL: one matrix);
+ *   layout 1: dx = dy w0, the input gradient ([dy0 | dy1 | dy2] [w0; w1; w2] with three matrices). */
+typedef struct digat_split_job {
+    const float *w0, *w1, *w2;   /* [rows, cols] each; w1, w2 both NULL or both given */
+    int32_t rows, cols, layout, reserved;
+    void* image;                 /* digat_split_job_bytes(rows, cols, layout, 1 or 3) bytes */
+} digat_split_job;
+size_t digat_split_job_bytes(int rows, int cols, int layout, int matrices);
+int digat_split_jobs(const digat_split_job* jobs, int njobs, void* stream);
+
 size_t digat_xattn_train_save_bytes(int B, int n, int d);
 size_t digat_xattn_train_workspace_bytes(int B, int n, int d);
+/* proj_image: NULL, or the layout-0 image of (W, F1, F2); bwd_image: NULL, or their layout-1 image */
 int digat_xattn_fwd_train(const float* X, const uint8_t* A, const float* ctx, const float* W, const float* bW, const float* F1,
                           const float* F2, const float* F3, const float* b3, const float* a, float* out, float p_alpha,
                           uint32_t seed, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          size_t workspace_bytes, const void* proj_image, void* stream);
 int digat_xattn_bwd(const float* dOut, const float* out, const float* X, const uint8_t* A, const float* ctx, const float* W,
                     const float* F1, const float* F2, const float* F3, const float* a, float p_alpha, const void* save,
                     size_t save_bytes, float* dX, float* dctx, float* dW, float* dbW, float* dF1, float* dF2, float* dF3,
-                    float* db3, float* da, int B, int n, int d, void* workspace, size_t workspace_bytes, void* stream);
+                    float* db3, float* da, int B, int n, int d, void* workspace, size_t workspace_bytes, const void* bwd_image,
+                    void* stream);
 /* a3 (graphEncoders.py:109-114): out = gate(drop_{p_gate}(W_g [l ; g] + b_g), l, g), l = X[:,0], g = candidate_attention(X, l). */
 size_t digat_news_ctx_train_save_bytes(int B, int N, int d);
 size_t digat_news_ctx_train_workspace_bytes(int B, int N, int d);
@@ -449,13 +469,14 @@ size_t digat_user_ctx_train_workspace_bytes(int B, int U, int H, int C1, int d);
 int digat_user_ctx_fwd_train(const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n, const float* Ku,
                              const float* Qu, const float* bQu, const float* Fa, const float* bFa, const float* Kua,
                              const float* Qua, const float* bQua, float* out, float p_topic, uint32_t seed, int B, int U, int H,
-                             int C1, int d, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                             int C1, int d, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                             const void* fa_image /* NULL, or the layout-0 image of Fa */, void* stream);
 int digat_user_ctx_bwd(const float* dout, const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n,
                        const float* Ku, const float* Qu, const float* Fa, const float* Kua, const float* Qua, float p_topic,
                        const void* save, size_t save_bytes, float* dXu, float* dc_n, float* dKu, float* dQu, float* dbQu,
                        float* dFa, float* dbFa, float* dKua, float* dQua, float* dbQua, int B, int U, int H, int C1, int d,
                        int accumulate_params /* as digat_news_ctx_bwd: the eight parameter gradients; dXu, dc_n are always written */,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, const void* fa_bwd_image /* NULL, or the layout-1 image of Fa */, void* stream);
 
 /* ---- H2: ranking + metrics of the dev/test driver  (util.py:70-80, evaluate.py:32-89) -------------------
  * scores [R] f32 in impression-major row order; impression_start [I+1] int64 (row offsets; impression i owns

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/digat_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTED), "ctypes signature table out of sync with the header"
-    assert L.digat_version() == _lib.ABI_VERSION == 3
+    assert L.digat_version() == _lib.ABI_VERSION == 4
     assert b"workspace" in L.digat_error_string(3)
 
 

@@ -130,6 +130,34 @@ def test_training_step_at_production_shapes_matches_reference_autograd():
         check_grad_digest(fx, name, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
 
 
+def test_split_images_made_once_per_step_change_no_bit(monkeypatch):
+    """digat_split_jobs: every split image of a step in one launch, handed to the entries (training.step_images), against each call
+    splitting its own weights: the same images, so loss and every gradient bit for bit — with dropout live, through both bindings;
+    and the launch is really taken (images for every layer of the user graph at these shapes)."""
+    from digat_amd import training
+    made = []
+    real = training.split_images
+    monkeypatch.setattr(training, "split_images", lambda jobs, dev: made.append(len(jobs)) or real(jobs, dev))
+
+    def grads(once, use_ext):
+        fx, enc, t, dims = build_default(dropout=0.2)
+        enc.split_weights_once_per_step = once
+        tape = iter(range(500, 1500))
+        monkeypatch.setattr(training, "_seed", lambda: next(tape))
+        if not use_ext:
+            monkeypatch.setattr(training._lib, "ext", lambda: None)
+        logits, loss, Xn, ue = run_step(enc, t, dims)
+        torch.cuda.synchronize()
+        return [loss.detach().clone(), Xn.grad.clone(), ue.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+
+    for use_ext in (True, False):
+        made.clear()
+        a, b = grads(True, use_ext), grads(False, use_ext)
+        assert made == [2 * 3], made          # the user graph's three layers, forward and backward images (news / topics: below 2 048 rows)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_bf16_training_precision_at_production_shapes():
     """BASELINE configs[4], training half: digat_set_train_precision(1) — one bf16 product for the >= 2048-row GEMMs, fp32
     master weights / accumulation / weight gradients.  Against the reference's fp32 autograd: loss within 1e-2 relative, every
