@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 /* 4 (round 6): digat_xattn_fwd_train / digat_xattn_bwd / digat_user_ctx_fwd_train / digat_user_ctx_bwd take a ready-made split image
- * (or NULL) before `stream`.  3: digat_params grew featureAffine_fsplit; digat_news_ctx_bwd / digat_user_ctx_bwd took
+ * (or NULL) before `stream`; the Eq. 8 pair takes the layer's input dropout (p_in, seed_in).  3: digat_params grew featureAffine_fsplit; digat_news_ctx_bwd / digat_user_ctx_bwd took
  * `accumulate_params` in round 5 and entry points were added without a bump: a loader built for one version must refuse a library
  * of another (digat_amd/_lib.py does) rather than shift arguments. */
 #define DIGAT_ABI_VERSION 4
@@ -437,13 +437,17 @@ int digat_split_jobs(const digat_split_job* jobs, int njobs, void* stream);
 
 size_t digat_xattn_train_save_bytes(int B, int n, int d);
 size_t digat_xattn_train_workspace_bytes(int B, int n, int d);
-/* proj_image: NULL, or the layout-0 image of (W, F1, F2); bwd_image: NULL, or their layout-1 image */
+/* proj_image: NULL, or the layout-0 image of (W, F1, F2); bwd_image: NULL, or their layout-1 image.
+ * p_in > 0 (round 6): X is the layer input BEFORE its input dropout; the entry applies drop_{p_in} with seed_in itself (the dropped
+ * input and its keep bytes travel in `save`), out = relu(drop_p(alpha) h) + drop(X), and the backward's dX is the gradient of the
+ * UNDROPPED X — the keep bytes are applied in the epilogue of the input-gradient product, no dropout launch.  p_in = 0: X is used
+ * as given (callers that drop their input themselves).  The backward takes the same p_in. */
 int digat_xattn_fwd_train(const float* X, const uint8_t* A, const float* ctx, const float* W, const float* bW, const float* F1,
                           const float* F2, const float* F3, const float* b3, const float* a, float* out, float p_alpha,
-                          uint32_t seed, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
+                          uint32_t seed, float p_in, uint32_t seed_in, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
                           size_t workspace_bytes, const void* proj_image, void* stream);
 int digat_xattn_bwd(const float* dOut, const float* out, const float* X, const uint8_t* A, const float* ctx, const float* W,
-                    const float* F1, const float* F2, const float* F3, const float* a, float p_alpha, const void* save,
+                    const float* F1, const float* F2, const float* F3, const float* a, float p_alpha, float p_in, const void* save,
                     size_t save_bytes, float* dX, float* dctx, float* dW, float* dbW, float* dF1, float* dF2, float* dF3,
                     float* db3, float* da, int B, int n, int d, void* workspace, size_t workspace_bytes, const void* bwd_image,
                     void* stream);

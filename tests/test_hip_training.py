@@ -360,15 +360,19 @@ def test_eq8_and_gat_layers_backward_at_the_largest_graphs(n, d):
         close(got[k], want_g[k].numpy(), f"GAT n={n} grad {k}")
 
 
-@pytest.mark.parametrize("n,d", [(67, 64), (10, 64), (128, 32)])
-def test_eq8_layer_with_attention_dropout_live(n, d, monkeypatch):
+@pytest.mark.parametrize("n,d,B,p_in", [(67, 64, 3, 0.0), (10, 64, 3, 0.0), (128, 32, 3, 0.0), (67, 80, 32, 0.25), (10, 64, 3, 0.25)])
+def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, monkeypatch):
     """digat_xattn_fwd_train / _bwd with the attention dropout LIVE (p = 0.3) against the oracle's autograd under the same keep bits:
     the dropout is applied inside the score kernels (the tile kernel at 67 and 128 nodes, the small-graph kernel — which also
-    aggregates in place — at 10), forward output and every gradient."""
+    aggregates in place — at 10), forward output and every gradient.  With p_in > 0 the library also applies the layer's INPUT
+    dropout and returns the gradient of the undropped input: through the epilogue of the bf16x6 input-gradient product at
+    32 x 67 = 2 144 rows, through a dropout launch below 2 048 rows."""
     from digat_amd import training
     from oracle import digat_oracle as O
     g = torch.Generator().manual_seed(n * 77 + d)
-    B, p_alpha, seed = 3, 0.3, 4242
+    p_alpha, seed, seed_in = 0.3, 4242, 977
+    if p_in > 0 and B * n >= 2048:
+        assert training._x3_ok(B * n, d, 3 * d)
     X = torch.randn(B, n, d, generator=g)
     A = (torch.rand(B, n, n, generator=g) < min(1.0, 6.0 / n))
     A |= torch.eye(n, dtype=torch.bool).unsqueeze(0)
@@ -383,18 +387,21 @@ def test_eq8_layer_with_attention_dropout_live(n, d, monkeypatch):
     p = {"user_graph_attention_" + names[k]: v.clone().requires_grad_(True) for k, v in w.items()}
     Xo, co = X.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
 
-    def drop(x, frac):          # the layer's input arrives already dropped (frac 0.5 site: identity here); alpha: the kernels' bits
-        return x if frac == 0.5 else O.hash_dropout(x.contiguous(), p_alpha, seed)
+    def drop(x, frac):          # frac 0.5: the layer's input site (identity when the caller drops it: p_in = 0); 1.0: alpha — the kernels' bits
+        if frac == 0.5:
+            return O.hash_dropout(x.contiguous(), p_in, seed_in) if p_in > 0 else x
+        return O.hash_dropout(x.contiguous(), p_alpha, seed)
 
     want_out = O.cross_graph_attention(p, "user", 0, Xo, A, co, drop=drop)
     (want_out * dOut).sum().backward()
     want = {"X": Xo.grad, "ctx": co.grad, **{k: p["user_graph_attention_" + names[k]].grad for k in w}}
 
-    monkeypatch.setattr(training, "_seed", lambda: seed)
+    seeds = iter([seed_in, seed] if p_in > 0 else [seed])
+    monkeypatch.setattr(training, "_seed", lambda: next(seeds))
     dv = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
     Ab = A.to(torch.uint8).to(DEV).contiguous()
     Xd, cd = X.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
-    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], p_alpha)
+    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], p_alpha, None, p_in)
     (out * dOut.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     close(out, want_out.detach().numpy(), f"Eq. 8 n={n} out under dropout", rtol=2e-5, atol=2e-5)
