@@ -360,11 +360,14 @@ def test_eq8_and_gat_layers_backward_at_the_largest_graphs(n, d):
         close(got[k], want_g[k].numpy(), f"GAT n={n} grad {k}")
 
 
-@pytest.mark.parametrize("n,d,B,p_in", [(67, 64, 3, 0.0), (10, 64, 3, 0.0), (128, 32, 3, 0.0), (67, 80, 32, 0.25), (10, 64, 3, 0.25)])
-def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, monkeypatch):
+@pytest.mark.parametrize("n,d,B,p_in,per_node", [(67, 64, 3, 0.0, 6), (10, 64, 3, 0.0, 6), (128, 32, 3, 0.0, 6), (67, 80, 32, 0.25, 6),
+                                                 (10, 64, 3, 0.25, 6), (67, 64, 3, 0.0, 40), (128, 400, 2, 0.0, 9)])
+def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, per_node, monkeypatch):
     """digat_xattn_fwd_train / _bwd with the attention dropout LIVE (p = 0.3) against the oracle's autograd under the same keep bits:
     the dropout is applied inside the score kernels (the tile kernel at 67 and 128 nodes, the small-graph kernel — which also
-    aggregates in place — at 10), forward output and every gradient.  With p_in > 0 the library also applies the layer's INPUT
+    aggregates in place — at 10), forward output and every gradient.  Graphs of more than 16 nodes go to the wave-per-centre kernel
+    when the batch's adjacency is sparse (~6 or ~9 entries per node here) and to the tile kernel + aggregation when it is not (~40):
+    the choice is made on the device.  With p_in > 0 the library also applies the layer's INPUT
     dropout and returns the gradient of the undropped input: through the epilogue of the bf16x6 input-gradient product at
     32 x 67 = 2 144 rows, through a dropout launch below 2 048 rows."""
     from digat_amd import training
@@ -374,9 +377,11 @@ def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, monkeypatch):
     if p_in > 0 and B * n >= 2048:
         assert training._x3_ok(B * n, d, 3 * d)
     X = torch.randn(B, n, d, generator=g)
-    A = (torch.rand(B, n, n, generator=g) < min(1.0, 6.0 / n))
+    A = (torch.rand(B, n, n, generator=g) < min(1.0, float(per_node) / n))
     A |= torch.eye(n, dtype=torch.bool).unsqueeze(0)
-    A[1, 0] = False
+    A[1, 0] = False                                                  # a centre without any entry: uniform attention (E5)
+    A[1, 1] = False
+    A[1, 1, 1] = True                                                # ... and one whose only entry is its self loop
     ctx = torch.randn(B, d, generator=g)
     dOut = torch.randn(B, n, d, generator=g)
     w = {k: (torch.randn(*shape, generator=g) * scale) for k, shape, scale in
