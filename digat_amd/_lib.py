@@ -156,15 +156,17 @@ _SIGNATURES = {
     "digat_xattn_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_xattn_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32, C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f]),
     "digat_xattn_bwd": (C.c_int, [_f] * 10 + [C.c_float, C.c_float, _f, C.c_size_t] + [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f, _f]),
+    "digat_row_logits_bwd": (C.c_int, [_f] * 5 + [C.c_int, C.c_int, _f]),
+    "digat_click_loss": (C.c_int, [_f, C.c_int, C.c_int, _f, _f, _f]),
     "digat_split_job_bytes": (C.c_size_t, [C.c_int] * 4),
     "digat_split_jobs": (C.c_int, [C.POINTER(SplitJob), C.c_int, _f]),
     "digat_news_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 3),
     "digat_news_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
-    "digat_news_ctx_fwd_train": (C.c_int, [_f] * 8 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f]),
+    "digat_news_ctx_fwd_train": (C.c_int, [_f] * 8 + [C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f]),
     "digat_news_ctx_bwd": (C.c_int, [_f] * 6 + [C.c_float, _f, C.c_size_t] + [_f] * 6 + [C.c_int] * 4 + [_f, C.c_size_t, _f]),
     "digat_user_ctx_train_save_bytes": (C.c_size_t, [C.c_int] * 5),
     "digat_user_ctx_train_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
-    "digat_user_ctx_fwd_train": (C.c_int, [_f] * 13 + [C.c_float, C.c_uint32] + [C.c_int] * 5 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f]),
+    "digat_user_ctx_fwd_train": (C.c_int, [_f] * 13 + [C.c_float, C.c_uint32] + [C.c_int] * 5 + [_f, C.c_size_t, _f, C.c_size_t, _f, _f, _f]),
     "digat_user_ctx_bwd": (C.c_int, [_f] * 10 + [C.c_float, _f, C.c_size_t] + [_f] * 10 + [C.c_int] * 6 + [_f, C.c_size_t, _f, _f]),
     "digat_profile_start": (C.c_int, [C.c_int]),
     "digat_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -161,6 +161,12 @@ at::Tensor scratch(const at::Tensor& like, size_t bytes) {       // stream-order
 }
 at::Tensor byte_buffer(const at::Tensor& like, size_t bytes) { return at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte)); }
 float* out_f32(at::Tensor& t) { return t.data_ptr<float>(); }
+// the context accumulated so far ([B,d], added to the call's output), or nothing
+const float* prev_of(const c10::optional<at::Tensor>& prev, const at::Tensor& like, int B, int d) {
+    if (!prev.has_value()) return nullptr;
+    shape(*prev, {B, d}, "prev");
+    return f32(*prev, like, "prev");
+}
 // a ready-made split image (digat_split_jobs), or nothing: a byte tensor on the inputs' device, at least `bytes` long
 const void* image_of(const c10::optional<at::Tensor>& image, const at::Tensor& like, size_t bytes) {
     if (!image.has_value()) return nullptr;
@@ -214,7 +220,8 @@ std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out,
 }
 
 std::tuple<at::Tensor, at::Tensor> news_ctx_fwd_train(const at::Tensor& X, const at::Tensor& mask, const at::Tensor& Kc, const at::Tensor& Qc,
-                                                      const at::Tensor& bQc, const at::Tensor& Wg, const at::Tensor& bg, double p, int64_t seed) {
+                                                      const at::Tensor& bQc, const at::Tensor& Wg, const at::Tensor& bg, double p, int64_t seed,
+                                                      const c10::optional<at::Tensor>& prev) {
     need(X.dim() == 3, "X [B,N,d] expected");
     const int B = (int)X.size(0), N = (int)X.size(1), d = (int)X.size(2);
     const c10::DeviceGuard guard(X.device());
@@ -224,7 +231,7 @@ std::tuple<at::Tensor, at::Tensor> news_ctx_fwd_train(const at::Tensor& X, const
     at::Tensor save = byte_buffer(X, nsave), ws = scratch(X, nws);
     check(digat_news_ctx_fwd_train(f32(X, X, "X"), bytes(mask, X, "mask"), f32(Kc, X, "Kc"), f32(Qc, X, "Qc"), f32(bQc, X, "bQc"), f32(Wg, X, "Wg"),
                                    f32(bg, X, "bg"), out_f32(out), (float)p, (uint32_t)seed, B, N, d, save.data_ptr(), nsave, ws.data_ptr(), nws,
-                                   stream_of(X)), "digat_news_ctx_fwd_train");
+                                   prev_of(prev, X, B, d), stream_of(X)), "digat_news_ctx_fwd_train");
     return {out, save};
 }
 
@@ -251,7 +258,8 @@ at::Tensor news_ctx_bwd(const at::Tensor& dout, const at::Tensor& X, const at::T
 std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, const at::Tensor& cat_mask, const at::Tensor& cat_idx, const at::Tensor& c_n,
                                                       const at::Tensor& Ku, const at::Tensor& Qu, const at::Tensor& bQu, const at::Tensor& Fa,
                                                       const at::Tensor& bFa, const at::Tensor& Kua, const at::Tensor& Qua, const at::Tensor& bQua,
-                                                      int64_t H, int64_t C1, double p, int64_t seed, const c10::optional<at::Tensor>& image) {
+                                                      int64_t H, int64_t C1, double p, int64_t seed, const c10::optional<at::Tensor>& image,
+                                                      const c10::optional<at::Tensor>& prev) {
     need(Xu.dim() == 3, "Xu [B,U,d] expected");
     const int B = (int)Xu.size(0), U = (int)Xu.size(1), d = (int)Xu.size(2);
     const c10::DeviceGuard guard(Xu.device());
@@ -265,7 +273,8 @@ std::tuple<at::Tensor, at::Tensor> user_ctx_fwd_train(const at::Tensor& Xu, cons
     check(digat_user_ctx_fwd_train(f32(Xu, Xu, "Xu"), bytes(cat_mask, Xu, "cat_mask"), i64(cat_idx, Xu, "cat_idx"), f32(c_n, Xu, "c_n"), f32(Ku, Xu, "Ku"),
                                    f32(Qu, Xu, "Qu"), f32(bQu, Xu, "bQu"), f32(Fa, Xu, "Fa"), f32(bFa, Xu, "bFa"), f32(Kua, Xu, "Kua"), f32(Qua, Xu, "Qua"),
                                    f32(bQua, Xu, "bQua"), out_f32(out), (float)p, (uint32_t)seed, B, U, (int)H, (int)C1, d, save.data_ptr(), nsave,
-                                   ws.data_ptr(), nws, image_of(image, Xu, digat_split_job_bytes(d, d, 0, 1)), stream_of(Xu)), "digat_user_ctx_fwd_train");
+                                   ws.data_ptr(), nws, image_of(image, Xu, digat_split_job_bytes(d, d, 0, 1)), prev_of(prev, Xu, B, d), stream_of(Xu)),
+          "digat_user_ctx_fwd_train");
     return {out, save};
 }
 

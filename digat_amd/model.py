@@ -81,6 +81,9 @@ class Model(nn.Module):
         news_rep, user_rep = self.graph_encoder(candidate_news_embedding, news_graph, news_graph_mask,
                                                 user_news_embedding, user_graph, user_category_mask,
                                                 user_category_indices)
+        if news_rep.is_cuda and news_rep.dtype == torch.float32 and news_rep.dim() == 2:
+            from .training import RowLogits          # the same dot products, one launch each way (digat_row_logits / digat_row_logits_bwd)
+            return RowLogits.apply(news_rep, user_rep).view([batch_size, news_num])
         news_rep = news_rep.view([batch_size, news_num, self.representation_dim])
         user_rep = user_rep.view([batch_size, news_num, self.representation_dim])
         return (user_rep * news_rep).sum(dim=2)

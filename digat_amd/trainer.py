@@ -24,7 +24,10 @@ from .evaluate import AvgMetric
 
 
 def training_loss(logits: torch.Tensor) -> torch.Tensor:
-    """trainer.py:100 — the clicked candidate is column 0."""
+    """trainer.py:100 — the clicked candidate is column 0.  On the GPU: the loss and its gradient from one launch (training.ClickLoss)."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[0] > 0:
+        from .training import ClickLoss
+        return ClickLoss.apply(logits)
     return (-torch.log_softmax(logits, dim=1).select(1, 0)).mean()
 
 

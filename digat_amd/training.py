@@ -171,6 +171,49 @@ class Dropout(Function):
         return dx, None
 
 
+class RowLogits(Function):
+    """logits[b] = sum_d user_ctx[b] news_ctx[b] (model.py:75), one launch each way (``digat_row_logits`` / ``digat_row_logits_bwd``)."""
+
+    @staticmethod
+    def forward(ctx, news_ctx, user_ctx):
+        news_ctx, user_ctx = _f(news_ctx), _f(user_ctx)
+        B, d = news_ctx.shape
+        logits = torch.empty(B, dtype=torch.float32, device=news_ctx.device)
+        if B:
+            _lib.check(L().digat_row_logits(news_ctx.data_ptr(), user_ctx.data_ptr(), logits.data_ptr(), B, d, S()), "digat_row_logits")
+        ctx.save_for_backward(news_ctx, user_ctx)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        news_ctx, user_ctx = ctx.saved_tensors
+        B, d = news_ctx.shape
+        dl = _f(dl)
+        dn, du = torch.empty_like(news_ctx), torch.empty_like(user_ctx)
+        _lib.check(L().digat_row_logits_bwd(dl.data_ptr(), news_ctx.data_ptr(), user_ctx.data_ptr(), dn.data_ptr(), du.data_ptr(), B, d, S()),
+                   "digat_row_logits_bwd")
+        return dn, du
+
+
+class ClickLoss(Function):
+    """trainer.py:100: mean(-log_softmax(logits [B,K], dim=1)[:, 0]) and its gradient from one launch (``digat_click_loss``)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = _f(logits)
+        B, K = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        _lib.check(L().digat_click_loss(logits.data_ptr(), B, K, loss.data_ptr(), dlogits.data_ptr(), S()), "digat_click_loss")
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss
+
+
 class TableLookup2(Function):
     """Rows of ONE embedding table for two id lists — the candidate graphs' nodes and the histories of a training batch
     (model.py:72-73 through a table-backed news encoder) — with ONE dense table gradient from one launch
@@ -529,9 +572,12 @@ class NewsCtxFused(Function):
     """compute_news_graph_context (graphEncoders.py:109-114), training mode."""
 
     @staticmethod
-    def forward(ctx, X, mask, Kc, Qc, bQc, Wg, bg, p_gate, sink=None):
+    def forward(ctx, X, mask, Kc, Qc, bQc, Wg, bg, p_gate, sink=None, prev=None):
+        """``prev``: None, or the context accumulated so far [B,d]: the call returns prev + context (graphEncoders.py:185) from the gate's
+        launch instead of a separate element-wise add; its gradient is the output's."""
         X = _f(X)
-        ctx.sink = sink
+        prev = _f(prev) if prev is not None else None
+        ctx.sink, ctx.has_prev = sink, prev is not None
         if sink is not None:
             sink.enter("news_ctx")
         B, N, d = X.shape
@@ -539,7 +585,7 @@ class NewsCtxFused(Function):
         E = _lib.ext()
         if E is not None:
             p = float(p_gate)
-            out, save = E.news_ctx_fwd_train(X, mask, Kc, Qc, bQc, Wg, bg, p, _seed() if p > 0 else 0)
+            out, save = E.news_ctx_fwd_train(X, mask, Kc, Qc, bQc, Wg, bg, p, _seed() if p > 0 else 0, prev)
             ctx.save_for_backward(X, mask, Kc, Qc, Wg, save)
             ctx.p, ctx.sizes = p, None
             return out
@@ -549,7 +595,7 @@ class NewsCtxFused(Function):
         p = float(p_gate)
         _lib.check(L().digat_news_ctx_fwd_train(X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), bQc.data_ptr(),
                                                 Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), p, _seed() if p > 0 else 0, B, N, d,
-                                                save.data_ptr(), nsave, ws.data_ptr(), nws, S()), "digat_news_ctx_fwd_train")
+                                                save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(prev), S()), "digat_news_ctx_fwd_train")
         ctx.save_for_backward(X, mask, Kc, Qc, Wg, save)
         ctx.p, ctx.sizes = p, (nsave, nws)
         return out
@@ -570,28 +616,32 @@ class NewsCtxFused(Function):
         E = _lib.ext()
         if E is not None and ctx.sizes is None:
             dX = E.news_ctx_bwd(dout, X, mask, Kc, Qc, Wg, ctx.p, save, list(grads), bool(acc))
+            dprev = dout if ctx.has_prev else None
             if sink is not None and not sink.end("news_ctx"):
-                return dX, None, None, None, None, None, None, None, None
-            return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None
+                return dX, None, None, None, None, None, None, None, None, dprev
+            return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None, dprev
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX = torch.empty_like(X)
         _lib.check(L().digat_news_ctx_bwd(dout.data_ptr(), X.data_ptr(), mask.data_ptr(), Kc.data_ptr(), Qc.data_ptr(), Wg.data_ptr(),
                                           ctx.p, save.data_ptr(), nsave, dX.data_ptr(), dKc.data_ptr(), dQc.data_ptr(), dbQc.data_ptr(),
                                           dWg.data_ptr(), dbg.data_ptr(), B, N, d, acc, ws.data_ptr(), nws, S()), "digat_news_ctx_bwd")
+        dprev = dout if ctx.has_prev else None
         if sink is not None and not sink.end("news_ctx"):
-            return dX, None, None, None, None, None, None, None, None
-        return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None
+            return dX, None, None, None, None, None, None, None, None, dprev
+        return dX, None, dKc, dQc, dbQc, dWg, dbg, None, None, dprev
 
 
 class UserCtxFused(Function):
     """compute_user_graph_context (graphEncoders.py:123-134), training mode."""
 
     @staticmethod
-    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic, sink=None, images=None):
-        """``images``: None, or (forward image, backward image) of featureAffine.weight from ``split_images``."""
+    def forward(ctx, Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, H, C1, p_topic, sink=None, images=None, prev=None):
+        """``images``: None, or (forward image, backward image) of featureAffine.weight from ``split_images``.
+        ``prev``: None, or the context accumulated so far [B,d]: the call returns prev + context (graphEncoders.py:186)."""
         Xu, c_n = _f(Xu), _f(c_n)
-        ctx.sink = sink
+        prev = _f(prev) if prev is not None else None
+        ctx.sink, ctx.has_prev = sink, prev is not None
         img_f, ctx.img_b = images if images is not None else (None, None)
         if sink is not None:
             sink.enter("user_ctx")
@@ -601,7 +651,7 @@ class UserCtxFused(Function):
         if E is not None:
             p = float(p_topic)
             out, save = E.user_ctx_fwd_train(Xu, cat_mask, cat_idx, c_n, Ku, Qu, bQu, Fa, bFa, Kua, Qua, bQua, int(H), int(C1), p,
-                                             _seed() if p > 0 else 0, img_f)
+                                             _seed() if p > 0 else 0, img_f, prev)
             ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
             ctx.p, ctx.sizes, ctx.dims = p, None, (H, C1)
             return out
@@ -613,7 +663,7 @@ class UserCtxFused(Function):
         _lib.check(L().digat_user_ctx_fwd_train(Xu.data_ptr(), cat_mask.data_ptr(), cat_idx.data_ptr(), c_n.data_ptr(), Ku.data_ptr(),
                                                 Qu.data_ptr(), bQu.data_ptr(), Fa.data_ptr(), bFa.data_ptr(), Kua.data_ptr(),
                                                 Qua.data_ptr(), bQua.data_ptr(), out.data_ptr(), p, _seed() if p > 0 else 0,
-                                                B, U, H, C1, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), S()),
+                                                B, U, H, C1, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), _lib.ptr(prev), S()),
                    "digat_user_ctx_fwd_train")
         ctx.save_for_backward(Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, save)
         ctx.p, ctx.sizes, ctx.dims = p, (nsave, nws), (H, C1)
@@ -636,9 +686,10 @@ class UserCtxFused(Function):
         if E is not None and ctx.sizes is None:
             dXu, dc = E.user_ctx_bwd(dout, Xu, cat_mask, cat_idx, c_n, Ku, Qu, Fa, Kua, Qua, ctx.p, save, list(grads), bool(acc), int(H), int(C1),
                                      ctx.img_b)
+            dprev = dout if ctx.has_prev else None
             if sink is not None and not sink.end("user_ctx"):
-                return (dXu, None, None, dc) + (None,) * 13
-            return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None
+                return (dXu, None, None, dc) + (None,) * 13 + (dprev,)
+            return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None, dprev
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dXu, dc = torch.empty_like(Xu), torch.empty_like(c_n)
@@ -647,9 +698,10 @@ class UserCtxFused(Function):
                                           save.data_ptr(), nsave, dXu.data_ptr(), dc.data_ptr(), dKu.data_ptr(), dQu.data_ptr(),
                                           dbQu.data_ptr(), dFa.data_ptr(), dbFa.data_ptr(), dKua.data_ptr(), dQua.data_ptr(),
                                           dbQua.data_ptr(), B, U, H, C1, d, acc, ws.data_ptr(), nws, _lib.ptr(ctx.img_b), S()), "digat_user_ctx_bwd")
+        dprev = dout if ctx.has_prev else None
         if sink is not None and not sink.end("user_ctx"):
-            return (dXu, None, None, dc) + (None,) * 13
-        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None
+            return (dXu, None, None, dc) + (None,) * 13 + (dprev,)
+        return dXu, None, None, dc, dKu, dQu, dbQu, dFa, dbFa, dKua, dQua, dbQua, None, None, None, None, None, dprev
 
 
 # --------------------------------------------------------------------------------------------------
@@ -702,16 +754,16 @@ def step_images(enc, rows_news, rows_user, rows_topics, dev):
     return out
 
 
-def news_graph_context(enc, X, mask_bytes, p, training=True, sink=None):
+def news_graph_context(enc, X, mask_bytes, p, training=True, sink=None, prev=None):
     ca, g = enc.candidate_attention, enc.news_graph_W
-    return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0, sink)
+    return NewsCtxFused.apply(X, mask_bytes, ca.K.weight, ca.Q.weight, ca.Q.bias, g.weight, g.bias, p / 2 if training else 0.0, sink, prev)
 
 
-def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True, sink=None, images=None):
+def user_graph_context(enc, Xu, cat_mask_bytes, cat_idx, c_n, p, training=True, sink=None, images=None, prev=None):
     ua, fa = enc.userAttention, enc.featureAffine
     return UserCtxFused.apply(Xu, cat_mask_bytes, cat_idx, c_n, enc.user_news_K.weight, enc.user_news_Q.weight, enc.user_news_Q.bias,
                               fa.weight, fa.bias, ua.K.weight, ua.Q.weight, ua.Q.bias, enc.max_history_num, enc.category_num,
-                              p if training else 0.0, sink, images)
+                              p if training else 0.0, sink, images, prev)
 
 
 def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True, images=None):
@@ -795,6 +847,6 @@ def digat_forward_train(enc, news_graph_embeddings, news_graph, news_graph_mask,
         Xn_next = graph_embeddings(enc, "news", i, Xn, An, c_u, p, images=img.get(("news", i)))
         Xu_next = graph_embeddings(enc, "user", i, Xu, Au, c_n, p, images=img.get(("user", i)))
         Xn, Xu = Xn_next, Xu_next
-        c_n = c_n + news_graph_context(enc, Xn, Mn, p, sink=sink)
-        c_u = c_u + user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink, images=fa)
+        c_n = news_graph_context(enc, Xn, Mn, p, sink=sink, prev=c_n)                   # c_n + ... (:185), added where the context is produced
+        c_u = user_graph_context(enc, Xu, cm, ci, c_n, p, sink=sink, images=fa, prev=c_u)   # c_u + ... (:186), of the UPDATED c_n
     return c_n, c_u

@@ -410,6 +410,13 @@ int digat_set_train_precision(int bf16);
  * training step at the same time. */
 enum { DIGAT_GEMM_BF16X6 = 0, DIGAT_GEMM_F16X3 = 1 };
 
+/* The step's head and tail around the encoder (round 6): the backward of digat_row_logits (model.py:75: logits = sum_d user_ctx news_ctx)
+ * and the loss of trainer.py:100 — mean over the B impressions of -log_softmax(logits [B,K])[:, 0] — with its gradient d loss / d logits
+ * [B,K] (written by the same launch: the caller scales it by the loss's incoming gradient). */
+int digat_row_logits_bwd(const float* dlogits, const float* news_ctx, const float* user_ctx, float* dnews, float* duser, int B, int d,
+                         void* stream);
+int digat_click_loss(const float* logits, int B, int K, float* loss, float* dlogits, void* stream);
+
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
  * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one
  * autograd.Function.  `save` is a caller-owned buffer carrying what the backward needs from the forward (private layout,
@@ -456,7 +463,8 @@ size_t digat_news_ctx_train_save_bytes(int B, int N, int d);
 size_t digat_news_ctx_train_workspace_bytes(int B, int N, int d);
 int digat_news_ctx_fwd_train(const float* X, const uint8_t* mask, const float* Kc, const float* Qc, const float* bQc,
                              const float* Wg, const float* bg, float* out, float p_gate, uint32_t seed, int B, int N, int d,
-                             void* save, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                             void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                             const float* prev /* NULL, or [B,d]: out = prev + context (graphEncoders.py:185; d prev = dout) */, void* stream);
 /* accumulate_params != 0: the PARAMETER gradients (dKc, dQc, dbQc, dWg, dbg) are added to what their buffers hold instead of
  * overwriting it — the context functions' weights are shared by the depth + 1 calls of a step (graphEncoders.py:177-187: one
  * candidate_attention / news_graph_W for every layer), so a caller can sum a step's gradients in one set of buffers inside the
@@ -474,7 +482,8 @@ int digat_user_ctx_fwd_train(const float* Xu, const uint8_t* cat_mask, const int
                              const float* Qu, const float* bQu, const float* Fa, const float* bFa, const float* Kua,
                              const float* Qua, const float* bQua, float* out, float p_topic, uint32_t seed, int B, int U, int H,
                              int C1, int d, void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
-                             const void* fa_image /* NULL, or the layout-0 image of Fa */, void* stream);
+                             const void* fa_image /* NULL, or the layout-0 image of Fa */,
+                             const float* prev /* NULL, or [B,d]: out = prev + context (graphEncoders.py:186) */, void* stream);
 int digat_user_ctx_bwd(const float* dout, const float* Xu, const uint8_t* cat_mask, const int64_t* cat_idx, const float* c_n,
                        const float* Ku, const float* Qu, const float* Fa, const float* Kua, const float* Qua, float p_topic,
                        const void* save, size_t save_bytes, float* dXu, float* dc_n, float* dKu, float* dQu, float* dbQu,

@@ -452,3 +452,26 @@ def test_table_lookup_of_two_id_lists_has_one_dense_gradient_equal_to_two_embedd
     t2 = table.clone().requires_grad_(True)
     (torch.nn.functional.embedding(ids_b, t2) * wb).sum().backward()
     close(enc.embed_table.grad, t2.grad.numpy(), "table gradient, second list only", rtol=1e-5, atol=1e-6)
+
+
+def test_step_head_and_tail_match_torch_autograd():
+    """training.RowLogits (model.py:75) and trainer.training_loss on the GPU (training.ClickLoss, trainer.py:100) against the torch
+    expressions they replace: values and gradients, with an incoming gradient other than 1."""
+    from digat_amd import training, trainer
+    g = torch.Generator().manual_seed(3)
+    B, K, d = 64, 5, 400
+    n, u = torch.randn(B * K, d, generator=g), torch.randn(B * K, d, generator=g) * 0.3
+    n0, u0 = n.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    lg0 = (u0.view(B, K, d) * n0.view(B, K, d)).sum(dim=2)
+    loss0 = (-torch.log_softmax(lg0, dim=1).select(1, 0)).mean()
+    (loss0 * 1.7).backward()
+    n1, u1 = n.to(DEV).requires_grad_(True), u.to(DEV).requires_grad_(True)
+    lg1 = training.RowLogits.apply(n1, u1).view(B, K)
+    loss1 = trainer.training_loss(lg1)
+    assert type(loss1.grad_fn).__name__.startswith("ClickLoss")
+    (loss1 * 1.7).backward()
+    torch.cuda.synchronize()
+    close(lg1, lg0.detach().numpy(), "logits", rtol=1e-5, atol=1e-5)
+    close(loss1, loss0.detach().numpy(), "loss", rtol=1e-6, atol=1e-6)
+    close(n1.grad, n0.grad.numpy(), "d news_ctx", rtol=2e-5, atol=1e-8)
+    close(u1.grad, u0.grad.numpy(), "d user_ctx", rtol=2e-5, atol=1e-8)
