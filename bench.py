@@ -556,8 +556,9 @@ def run_training(W, args, D: Dist, steps, warmup):
                     "algorithmic_flops_per_step": flops, "executed_flops_per_step": nprod * flops,
                     "gemm_launch_ms_per_step": gemm_ms, "gemm_hbm_bytes_per_step": gemm_bytes,
                     "frac_within_the_gemm_launches": nprod * flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gemm_ms > 0 else None,
-                    "note": "a 320-row step is ~250 launches of 5-80 us: the step is bound by launch cadence and by the dense Eq. 8 "
-                            "backward (no sparse / live-row kernels in training yet), not by the matrix cores"}
+                    "note": "a 320-row step is ~300 launches of 4-140 us, back to back on one stream: the step is bound by the latency of "
+                            "its many small launches ([B,d] linears, reductions) and by the three 21 440-row products per user-graph layer, "
+                            "not by the matrix cores' peak; the user graph's Eq. 8 runs on the entry-wise kernels forward and backward"}
     ddp = None
     if D.world > 1 and hasattr(tr.model, "_get_ddp_logging_data"):
         try:          # DistributedDataParallel's own measurements (nanoseconds, averaged over the sampled iterations)

@@ -423,7 +423,7 @@ int digat_split_jobs(const digat_split_job* jobs, int njobs, void* stream) {
         wsplit_note(j.image, 0);
     }
     long bx = (most + 255) / 256;
-    if (bx > 512) bx = 512;
+    if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(split_weights_jobs_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, all);
     DIGAT_CHECK_LAUNCH();
     return DIGAT_OK;
