@@ -178,7 +178,7 @@ const void* image_of(const c10::optional<at::Tensor>& image, const at::Tensor& l
 std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec, const at::Tensor& W,
                                                    const at::Tensor& bW, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3,
                                                    const at::Tensor& b3, const at::Tensor& a, double p, int64_t seed, double p_in, int64_t seed_in,
-                                                   const c10::optional<at::Tensor>& image) {
+                                                   const c10::optional<at::Tensor>& image, int64_t xattn_mode) {
     need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
     const c10::DeviceGuard guard(Xd.device());          // allocations and the launch on the input's device, whatever the current one is
@@ -190,15 +190,15 @@ std::tuple<at::Tensor, at::Tensor> xattn_fwd_train(const at::Tensor& Xd, const a
     check(digat_xattn_fwd_train(f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"), f32(bW, Xd, "bW"), f32(F1, Xd, "F1"),
                                 f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(b3, Xd, "b3"), f32(a, Xd, "a"), out_f32(out), (float)p, (uint32_t)seed, (float)p_in,
                                 (uint32_t)seed_in, B, n, d,
-                                save.data_ptr(), nsave, ws.data_ptr(), nws, image_of(image, Xd, digat_split_job_bytes(d, d, 0, 3)), stream_of(Xd)),
-          "digat_xattn_fwd_train");
+                                save.data_ptr(), nsave, ws.data_ptr(), nws, image_of(image, Xd, digat_split_job_bytes(d, d, 0, 3)), (int)xattn_mode,
+                                stream_of(Xd)), "digat_xattn_fwd_train");
     return {out, save};
 }
 
 // -> dX, dctx, dW3 ([3,d,d]: dW, dF1, dF2 written in place as one product), dbW, dF3, db3, da
 std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out, const at::Tensor& Xd, const at::Tensor& A, const at::Tensor& cvec,
                                   const at::Tensor& W, const at::Tensor& F1, const at::Tensor& F2, const at::Tensor& F3, const at::Tensor& a, double p,
-                                  double p_in, const at::Tensor& save, const c10::optional<at::Tensor>& image) {
+                                  double p_in, const at::Tensor& save, const c10::optional<at::Tensor>& image, int64_t xattn_mode) {
     need(Xd.dim() == 3, "Xd [B,n,d] expected");
     const int B = (int)Xd.size(0), n = (int)Xd.size(1), d = (int)Xd.size(2);
     const c10::DeviceGuard guard(Xd.device());
@@ -215,7 +215,7 @@ std::vector<at::Tensor> xattn_bwd(const at::Tensor& dOut, const at::Tensor& out,
     check(digat_xattn_bwd(f32(dOut, Xd, "dOut"), f32(out, Xd, "out"), f32(Xd, Xd, "Xd"), bytes(A, Xd, "A"), f32(cvec, Xd, "ctx"), f32(W, Xd, "W"),
                           f32(F1, Xd, "F1"), f32(F2, Xd, "F2"), f32(F3, Xd, "F3"), f32(a, Xd, "a"), (float)p, (float)p_in, save.data_ptr(), nsave, out_f32(dX),
                           out_f32(dc), w3, out_f32(dbW), w3 + dd, w3 + 2 * dd, out_f32(dF3), out_f32(db3), out_f32(da), B, n, d, ws.data_ptr(), nws,
-                          image_of(image, Xd, digat_split_job_bytes(d, d, 1, 3)), stream_of(Xd)), "digat_xattn_bwd");
+                          image_of(image, Xd, digat_split_job_bytes(d, d, 1, 3)), (int)xattn_mode, stream_of(Xd)), "digat_xattn_bwd");
     return {dX, dc, dW3, dbW, dF3, db3, da};
 }
 

@@ -115,6 +115,14 @@ class Trainer:
         self.epoch_not_increase = 0
         self.best_state = None
         from . import util
+        # Eq. 8 of the user graph in training: the corpus is known here, so the entry-wise / all-pairs choice the library would otherwise
+        # make on the device per batch (a decision launch, and the launches of the side not taken returning at once: ~40 us per layer)
+        # is made once, on the host, as util.prepare_news_side does for scoring; an explicit encoder.user_xattn_mode wins
+        enc = getattr(model, "graph_encoder", None)
+        if enc is not None and hasattr(enc, "corpus_xattn_hint") and "user" not in enc.corpus_xattn_hint and dc is not None \
+                and getattr(dc, "user_graph", None) is not None and dc.user_graph.numel() > 0:
+            per_node = float(dc.user_graph.sum(dtype=torch.float64) / (dc.user_graph.shape[0] * dc.user_graph.shape[1]))
+            enc.corpus_xattn_hint = dict(enc.corpus_xattn_hint, user="sparse" if per_node <= util.SPARSE_ENTRIES_PER_NODE else "dense")
         util.freeze_host_heap()           # the corpus's host-side structures: out of the garbage collector's walks (util.freeze_host_heap)
 
     def lr_decay(self):

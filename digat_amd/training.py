@@ -423,20 +423,23 @@ class XattnFused(Function):
     relu'(K3+K1+K2)), the three projection backwards, K3's — in ``digat_xattn_bwd``."""
 
     @staticmethod
-    def forward(ctx, Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p_alpha, images=None, p_in=0.0):
+    def forward(ctx, Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p_alpha, images=None, p_in=0.0, xattn_mode=0):
         """``images``: None, or (forward image, backward image) of (W, F1, F2) from ``split_images`` (either may be None).
         ``p_in`` > 0: ``Xd`` is the layer input BEFORE its input dropout and the library applies drop_{p_in} itself (its backward rides
-        in the epilogue of the input-gradient product); 0: the caller has dropped the input."""
+        in the epilogue of the input-gradient product); 0: the caller has dropped the input.
+        ``xattn_mode``: 0 = the library decides per batch on the device between the entry-wise and the all-pairs Eq. 8 kernels (graphs of
+        more than 16 nodes), 1 = entry-wise (sparse corpus), 2 = all-pairs — the same function, a choice of speed."""
         Xd, cvec = _f(Xd), _f(cvec)
         B, n, d = Xd.shape
         dev = Xd.device
         p, p_in = float(p_alpha), float(p_in)
         img_f, ctx.img_b = images if images is not None else (None, None)
+        ctx.mode = int(xattn_mode)
         seed_in = _seed() if p_in > 0 else 0          # the input dropout's site comes first (graphEncoders.py:145 before :152)
         seed = _seed() if p > 0 else 0
         E = _lib.ext()
         if E is not None:          # the thin torch extension: tensors in, out / save allocated there (the same C entry)
-            out, save = E.xattn_fwd_train(Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p, seed, p_in, seed_in, img_f)
+            out, save = E.xattn_fwd_train(Xd, A, cvec, W, bW, F1, F2, F3, b3, a, p, seed, p_in, seed_in, img_f, ctx.mode)
             ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
             ctx.p, ctx.p_in, ctx.sizes = p, p_in, None
             return out
@@ -445,7 +448,7 @@ class XattnFused(Function):
         save, ws = _save_buffer(nsave, dev), _lib.workspace(nws, dev, "train")
         _lib.check(L().digat_xattn_fwd_train(Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(), bW.data_ptr(), F1.data_ptr(),
                                              F2.data_ptr(), F3.data_ptr(), b3.data_ptr(), a.data_ptr(), out.data_ptr(), p,
-                                             seed, p_in, seed_in, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), S()),
+                                             seed, p_in, seed_in, B, n, d, save.data_ptr(), nsave, ws.data_ptr(), nws, _lib.ptr(img_f), ctx.mode, S()),
                    "digat_xattn_fwd_train")
         ctx.save_for_backward(Xd, A, cvec, W, F1, F2, F3, a, out, save)
         ctx.p, ctx.p_in, ctx.sizes = p, p_in, (nsave, nws)
@@ -459,8 +462,8 @@ class XattnFused(Function):
         dOut = _f(dOut)
         E = _lib.ext()
         if E is not None and ctx.sizes is None:
-            dX, dc, dW3, dbW, dF3, db3, da = E.xattn_bwd(dOut, out, Xd, A, cvec, W, F1, F2, F3, a, ctx.p, ctx.p_in, save, ctx.img_b)
-            return dX, None, dc, dW3[0], dbW, dW3[1], dW3[2], dF3, db3, da.view_as(a), None, None, None
+            dX, dc, dW3, dbW, dF3, db3, da = E.xattn_bwd(dOut, out, Xd, A, cvec, W, F1, F2, F3, a, ctx.p, ctx.p_in, save, ctx.img_b, ctx.mode)
+            return dX, None, dc, dW3[0], dbW, dW3[1], dW3[2], dF3, db3, da.view_as(a), None, None, None, None
         nsave, nws = ctx.sizes
         ws = _lib.workspace(nws, dev, "train")
         dX, dc = torch.empty_like(Xd), torch.empty_like(cvec)
@@ -472,9 +475,9 @@ class XattnFused(Function):
         _lib.check(L().digat_xattn_bwd(dOut.data_ptr(), out.data_ptr(), Xd.data_ptr(), A.data_ptr(), cvec.data_ptr(), W.data_ptr(),
                                        F1.data_ptr(), F2.data_ptr(), F3.data_ptr(), a.data_ptr(), ctx.p, ctx.p_in, save.data_ptr(), nsave,
                                        dX.data_ptr(), dc.data_ptr(), dW.data_ptr(), dbW.data_ptr(), dF1.data_ptr(), dF2.data_ptr(),
-                                       dF3.data_ptr(), db3.data_ptr(), da.data_ptr(), B, n, d, ws.data_ptr(), nws, _lib.ptr(ctx.img_b), S()),
+                                       dF3.data_ptr(), db3.data_ptr(), da.data_ptr(), B, n, d, ws.data_ptr(), nws, _lib.ptr(ctx.img_b), ctx.mode, S()),
                    "digat_xattn_bwd")
-        return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None, None, None
+        return dX, None, dc, dW, dbW, dF1, dF2, dF3, db3, da.view_as(a), None, None, None, None
 
 
 class GatFused(Function):
@@ -773,7 +776,8 @@ def graph_embeddings(enc, g, i, X, A_bytes, ctx_vec, p, training=True, images=No
     return XattnFused.apply(X, A_bytes, ctx_vec, W.weight, W.bias,
                             getattr(enc, f"{g}_graph_attention_ffn1")[i].weight,
                             getattr(enc, f"{g}_graph_attention_ffn2")[i].weight, F3.weight, F3.bias,
-                            getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0, images, p / 2 if training else 0.0)
+                            getattr(enc, f"{g}_graph_attention_a")[i].weight, p if training else 0.0, images, p / 2 if training else 0.0,
+                            {"auto": 0, "sparse": 1, "dense": 2}[enc.resolved_xattn_mode(g)] if hasattr(enc, "resolved_xattn_mode") else 0)
 
 
 def gat_embeddings(enc, g, i, X, A_bytes, p, training=True):

@@ -448,16 +448,22 @@ size_t digat_xattn_train_workspace_bytes(int B, int n, int d);
  * p_in > 0 (round 6): X is the layer input BEFORE its input dropout; the entry applies drop_{p_in} with seed_in itself (the dropped
  * input and its keep bytes travel in `save`), out = relu(drop_p(alpha) h) + drop(X), and the backward's dX is the gradient of the
  * UNDROPPED X — the keep bytes are applied in the epilogue of the input-gradient product, no dropout launch.  p_in = 0: X is used
- * as given (callers that drop their input themselves).  The backward takes the same p_in. */
+ * as given (callers that drop their input themselves).  The backward takes the same p_in.
+ * xattn_mode (graphs of more than 16 nodes; both directions take the same value): which kernels evaluate Eq. 8 — a choice of speed
+ * only, the function is the same.  DIGAT_TRAIN_XATTN_AUTO: decided on the device per batch from a sample of the adjacency (the
+ * entry-wise kernels when it holds at most ~20 entries per node, the all-pairs kernels otherwise; the launches of the side not
+ * taken return at once); _SPARSE: the entry-wise kernels (a wave per centre / per node over the adjacency's entries), _DENSE: the
+ * all-pairs kernels — unguarded: a caller that knows its corpus saves the decision and the empty launches. */
+enum { DIGAT_TRAIN_XATTN_AUTO = 0, DIGAT_TRAIN_XATTN_SPARSE = 1, DIGAT_TRAIN_XATTN_DENSE = 2 };
 int digat_xattn_fwd_train(const float* X, const uint8_t* A, const float* ctx, const float* W, const float* bW, const float* F1,
                           const float* F2, const float* F3, const float* b3, const float* a, float* out, float p_alpha,
                           uint32_t seed, float p_in, uint32_t seed_in, int B, int n, int d, void* save, size_t save_bytes, void* workspace,
-                          size_t workspace_bytes, const void* proj_image, void* stream);
+                          size_t workspace_bytes, const void* proj_image, int xattn_mode, void* stream);
 int digat_xattn_bwd(const float* dOut, const float* out, const float* X, const uint8_t* A, const float* ctx, const float* W,
                     const float* F1, const float* F2, const float* F3, const float* a, float p_alpha, float p_in, const void* save,
                     size_t save_bytes, float* dX, float* dctx, float* dW, float* dbW, float* dF1, float* dF2, float* dF3,
                     float* db3, float* da, int B, int n, int d, void* workspace, size_t workspace_bytes, const void* bwd_image,
-                    void* stream);
+                    int xattn_mode, void* stream);
 /* a3 (graphEncoders.py:109-114): out = gate(drop_{p_gate}(W_g [l ; g] + b_g), l, g), l = X[:,0], g = candidate_attention(X, l). */
 size_t digat_news_ctx_train_save_bytes(int B, int N, int d);
 size_t digat_news_ctx_train_workspace_bytes(int B, int N, int d);

@@ -360,14 +360,16 @@ def test_eq8_and_gat_layers_backward_at_the_largest_graphs(n, d):
         close(got[k], want_g[k].numpy(), f"GAT n={n} grad {k}")
 
 
-@pytest.mark.parametrize("n,d,B,p_in,per_node", [(67, 64, 3, 0.0, 6), (10, 64, 3, 0.0, 6), (128, 32, 3, 0.0, 6), (67, 80, 32, 0.25, 6),
-                                                 (10, 64, 3, 0.25, 6), (67, 64, 3, 0.0, 40), (128, 400, 2, 0.0, 9)])
-def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, per_node, monkeypatch):
+@pytest.mark.parametrize("n,d,B,p_in,per_node,mode", [(67, 64, 3, 0.0, 6, 0), (10, 64, 3, 0.0, 6, 0), (128, 32, 3, 0.0, 6, 0), (67, 80, 32, 0.25, 6, 0),
+                                                      (10, 64, 3, 0.25, 6, 0), (67, 64, 3, 0.0, 40, 0), (128, 400, 2, 0.0, 9, 0),
+                                                      (67, 64, 3, 0.0, 6, 1), (67, 64, 3, 0.0, 40, 1), (67, 64, 3, 0.0, 6, 2), (10, 64, 3, 0.0, 6, 1)])
+def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, per_node, mode, monkeypatch):
     """digat_xattn_fwd_train / _bwd with the attention dropout LIVE (p = 0.3) against the oracle's autograd under the same keep bits:
     the dropout is applied inside the score kernels (the tile kernel at 67 and 128 nodes, the small-graph kernel — which also
     aggregates in place — at 10), forward output and every gradient.  Graphs of more than 16 nodes go to the wave-per-centre kernel
     when the batch's adjacency is sparse (~6 or ~9 entries per node here) and to the tile kernel + aggregation when it is not (~40):
-    the choice is made on the device.  With p_in > 0 the library also applies the layer's INPUT
+    the choice is made on the device (mode 0) or by the caller (1: entry-wise, also on the dense graph; 2: all-pairs, also on the
+    sparse one — the same function either way).  With p_in > 0 the library also applies the layer's INPUT
     dropout and returns the gradient of the undropped input: through the epilogue of the bf16x6 input-gradient product at
     32 x 67 = 2 144 rows, through a dropout launch below 2 048 rows."""
     from digat_amd import training
@@ -406,7 +408,7 @@ def test_eq8_layer_with_attention_dropout_live(n, d, B, p_in, per_node, monkeypa
     dv = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
     Ab = A.to(torch.uint8).to(DEV).contiguous()
     Xd, cd = X.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
-    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], p_alpha, None, p_in)
+    out = training.XattnFused.apply(Xd, Ab, cd, dv["W"], dv["bW"], dv["F1"], dv["F2"], dv["F3"], dv["b3"], dv["a"], p_alpha, None, p_in, mode)
     (out * dOut.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     close(out, want_out.detach().numpy(), f"Eq. 8 n={n} out under dropout", rtol=2e-5, atol=2e-5)

@@ -49,7 +49,7 @@ plain = json.loads(open("$OUT/train_plain.json").read().strip().splitlines()[-1]
 steps = 30 + 5 + 3            # timed + warm-up + the profiled MFMA pass; the clock-based pre-warm adds more: calls per step are quoted per TIMED-RUN step count below
 tot_calls = sum(int(r["Calls"]) for r in rows); tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
 # the number of steps in the trace = calls of a once-per-step kernel
-per_step = max(1, min(int(r["Calls"]) for r in rows if "xattn_score_kernel" in r["Name"]) // 3)
+per_step = max(1, min(int(r["Calls"]) for r in rows if "click_loss_kernel" in r["Name"]))      # once per step
 print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --steps 30 --warmup 5 --impressions 4096  (pre-warm steps included)")
 print("# %d training steps of 64 x 5 rows in the trace: %.3f ms of kernel time and %.0f launches per step; the traced run's own line: %.3f ms per step; UNTRACED run (60 steps): %.3f ms per step" % (per_step, tot_ns / per_step / 1e6, tot_calls / per_step, line["ms_per_step"], plain["ms_per_step"]))
 print("%-72s %10s %9s %8s" % ("kernel", "calls/step", "us/step", "avg us"))
