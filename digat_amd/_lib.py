@@ -157,6 +157,8 @@ _SIGNATURES = {
     "digat_xattn_fwd_train": (C.c_int, [_f] * 11 + [C.c_float, C.c_uint32, C.c_float, C.c_uint32] + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_size_t, _f, C.c_int,
                                         _f]),
     "digat_xattn_bwd": (C.c_int, [_f] * 10 + [C.c_float, C.c_float, _f, C.c_size_t] + [_f] * 9 + [C.c_int] * 3 + [_f, C.c_size_t, _f, C.c_int, _f]),
+    "digat_opt_chunk": (C.c_int, []),
+    "digat_clip_adam_step": (C.c_int, [_f, _f, _f, C.c_int, _f] + [C.c_float] * 5 + [C.c_int, _f]),
     "digat_row_logits_bwd": (C.c_int, [_f] * 5 + [C.c_int, C.c_int, _f]),
     "digat_click_loss": (C.c_int, [_f, C.c_int, C.c_int, _f, _f, _f]),
     "digat_split_job_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -100,7 +100,13 @@ class Trainer:
         # the same arithmetic per element
         groups = parameter_groups(self.model, getattr(config, "weight_decay", 0.0))
         on_gpu = all(p.is_cuda for g in groups for p in g["params"])
-        self.optimizer = optim.Adam(groups, lr=config.lr, **({"fused": True} if on_gpu and getattr(config, "fused_adam", True) else {}))
+        # round 6: on the GPU the clipping and the update are ONE pass over (p, g, m, v) + two small launches for the norm (optim.ClipAdam:
+        # 3 launches where clip_grad_norm_ + the fused Adam are 15); config.optimizer_impl = "torch" keeps torch's pair
+        if on_gpu and getattr(config, "optimizer_impl", "hip") == "hip" and all(p.dtype == torch.float32 for g in groups for p in g["params"]):
+            from .optim import ClipAdam
+            self.optimizer = ClipAdam(groups, lr=config.lr)
+        else:
+            self.optimizer = optim.Adam(groups, lr=config.lr, **({"fused": True} if on_gpu and getattr(config, "fused_adam", True) else {}))
         self.gradient_clip_norm = getattr(config, "gradient_clip_norm", 1.0)
         self.decay_epoch = lr_decay_epoch(self.epochs)
         self.dc, self.train_set = dc, train_set
@@ -182,9 +188,12 @@ class Trainer:
         loss = training_loss(logits)
         self.optimizer.zero_grad()
         loss.backward()
-        if self.gradient_clip_norm > 0:
-            nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip_norm)
-        self.optimizer.step()
+        if hasattr(self.optimizer, "_chunk"):                           # optim.ClipAdam: the clipping coefficient is applied inside the update
+            self.optimizer.step(max_norm=self.gradient_clip_norm)
+        else:
+            if self.gradient_clip_norm > 0:
+                nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip_norm)
+            self.optimizer.step()
         return float(loss.item()) if read_loss else loss.detach()
 
     def _criterion(self, metrics):

@@ -417,6 +417,16 @@ int digat_row_logits_bwd(const float* dlogits, const float* news_ctx, const floa
                          void* stream);
 int digat_click_loss(const float* logits, int B, int K, float* loss, float* dlogits, void* stream);
 
+/* The optimiser's step (trainer.py:30, :103-105: clip_grad_norm_ + Adam) as three launches: the squared gradient norm per chunk, its
+ * total, and one pass over (p, g, m, v) that applies the clipping coefficient min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no
+ * clipping) and torch.optim.Adam's update (coupled weight decay per tensor; bias corrections from `step` >= 1).  `tensors`: an array
+ * of digat_opt_tensor in DEVICE memory; chunk c covers the digat_opt_chunk() elements of tensor chunk_tensor[c] from chunk_off[c];
+ * scratch: nchunks + 1 floats.  The gradients are read, not rewritten. */
+typedef struct digat_opt_tensor { float* p; const float* g; float* m; float* v; int64_t n; float weight_decay; int32_t pad; } digat_opt_tensor;
+int digat_opt_chunk(void);
+int digat_clip_adam_step(const void* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off, int nchunks, float* scratch, float max_norm,
+                         float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* ---- training: the three functions of the path as one forward and one backward call each ----------------
  * Composed on the C++ side from the primitives above (digat_train_abi.inc); digat_amd/training.py wraps each pair in one
  * autograd.Function.  `save` is a caller-owned buffer carrying what the backward needs from the forward (private layout,

@@ -477,3 +477,35 @@ def test_step_head_and_tail_match_torch_autograd():
     close(loss1, loss0.detach().numpy(), "loss", rtol=1e-6, atol=1e-6)
     close(n1.grad, n0.grad.numpy(), "d news_ctx", rtol=2e-5, atol=1e-8)
     close(u1.grad, u0.grad.numpy(), "d user_ctx", rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("max_norm,wd", [(1.0, 0.0), (0.0, 0.0), (0.05, 0.01)])
+def test_clip_adam_matches_clip_grad_norm_and_torch_adam(max_norm, wd):
+    """optim.ClipAdam (clipping by the global norm + Adam in three launches) against clip_grad_norm_ + torch.optim.Adam on the CPU over
+    several steps: tensors of odd sizes (the vector path's tails, a tensor smaller than a chunk, one of several chunks, an unaligned
+    view), two weight-decay groups, gradients large enough to be clipped."""
+    from digat_amd.optim import ClipAdam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(400, 400), (400,), (3,), (70001,), (1, 400), (33, 17)]
+    base = [torch.randn(*s_, generator=g) for s_ in shapes]
+    ref = [b.clone().requires_grad_(True) for b in base]
+    big = torch.zeros(70001 + 3, device=DEV)
+    dev = [b.to(DEV).requires_grad_(True) for b in base]
+    opt_ref = torch.optim.Adam([{"params": ref[:3], "weight_decay": wd}, {"params": ref[3:], "weight_decay": 0.0}], lr=1e-2)
+    opt_dev = ClipAdam([{"params": dev[:3], "weight_decay": wd}, {"params": dev[3:], "weight_decay": 0.0}], lr=1e-2)
+    for step in range(4):
+        grads = [torch.randn(*s_, generator=g) * (3.0 if step % 2 == 0 else 0.01) for s_ in shapes]
+        for p, q, gr in zip(ref, dev, grads):
+            p.grad = gr.clone()
+            q.grad = gr.to(DEV)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        opt_ref.step()
+        opt_dev.step(max_norm=max_norm)
+        torch.cuda.synchronize()
+        for k, (p, q) in enumerate(zip(ref, dev)):
+            # (where coef g and wd p nearly cancel, g' is of the size of eps and the update m / (sqrt(v) + eps) feels the last bit of the
+            # norm — summed per chunk here, per tensor in torch: 2e-6 of an O(1) parameter in the third case)
+            close(q, p.detach().numpy(), f"step {step} tensor {k}", rtol=2e-5, atol=1e-6)
+        assert torch.equal(dev[0].grad.cpu(), grads[0])            # the gradients are read, not rescaled
+    del big
