@@ -509,3 +509,53 @@ def test_clip_adam_matches_clip_grad_norm_and_torch_adam(max_norm, wd):
             close(q, p.detach().numpy(), f"step {step} tensor {k}", rtol=2e-5, atol=1e-6)
         assert torch.equal(dev[0].grad.cpu(), grads[0])            # the gradients are read, not rescaled
     del big
+
+
+def test_round6_entry_points_reject_bad_arguments_and_handle_empty_work():
+    """digat_split_jobs / digat_embedding_bwd_unsorted / digat_clip_adam_step / digat_click_loss: error codes for bad arguments (no launch),
+    empty work is a no-op, ids outside the table receive nothing."""
+    import ctypes as C
+    from digat_amd import _lib
+    L = _lib.lib()
+    ERR_ARG = 1
+    d = 80
+    w = torch.randn(d, d, device=DEV)
+    img = torch.empty(L.digat_split_job_bytes(d, d, 0, 1), dtype=torch.uint8, device=DEV)
+    assert L.digat_split_job_bytes(d, d, 2, 1) == 0 and L.digat_split_job_bytes(d, d, 0, 2) == 0
+    job = (_lib.SplitJob * 1)(_lib.SplitJob(w.data_ptr(), None, None, d, d, 0, 0, img.data_ptr()))
+    assert L.digat_split_jobs(job, 0, None) == 0
+    assert L.digat_split_jobs(None, 1, None) == ERR_ARG
+    assert L.digat_split_jobs(job, 25, None) == ERR_ARG
+    bad = (_lib.SplitJob * 1)(_lib.SplitJob(w.data_ptr(), w.data_ptr(), None, d, d, 0, 0, img.data_ptr()))      # two of three matrices
+    assert L.digat_split_jobs(bad, 1, None) == ERR_ARG
+    bad = (_lib.SplitJob * 1)(_lib.SplitJob(w.data_ptr(), None, None, d, d, 3, 0, img.data_ptr()))
+    assert L.digat_split_jobs(bad, 1, None) == ERR_ARG
+    # the image of one job equals the per-call split of the same weight (digat_split_weights, bf16x6)
+    ref = torch.empty_like(img)
+    assert L.digat_split_jobs(job, 1, _lib.stream_ptr()) == 0
+    assert L.digat_split_weights(w.data_ptr(), d, d, ref.data_ptr(), 0, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(img, ref)
+    # table gradient: nothing to do, and ids outside [0, V)
+    V, dm = 50, 16
+    table_grad = torch.zeros(V, dm, device=DEV)
+    ws = torch.empty(L.digat_embedding_bwd_unsorted_workspace_bytes(8, dm, V), dtype=torch.uint8, device=DEV)
+    assert L.digat_embedding_bwd_unsorted(None, None, dm, 0, None, None, dm, 0, dm, V, table_grad.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    ids = torch.tensor([3, -1, 70, 3, 49, 0, 3, 49], dtype=torch.int64, device=DEV)
+    g = torch.arange(8 * dm, dtype=torch.float32, device=DEV).view(8, dm)
+    assert L.digat_embedding_bwd_unsorted(ids.data_ptr(), g.data_ptr(), dm, 8, None, None, dm, 0, dm, V, table_grad.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    want = torch.zeros(V, dm)
+    for k, i in enumerate(ids.tolist()):
+        if 0 <= i < V:
+            want[i] += g[k].cpu()
+    assert torch.equal(table_grad.cpu(), want)
+    assert L.digat_embedding_bwd_unsorted(ids.data_ptr(), g.data_ptr(), dm, 8, None, None, dm, 0, 6, V, table_grad.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), None) == 2                                        # dm % 4: SHAPE
+    assert L.digat_embedding_bwd_unsorted(ids.data_ptr(), g.data_ptr(), dm, 8, None, None, dm, 0, dm, V, table_grad.data_ptr(), ws.data_ptr(), 16,
+                                          None) == 3                                                    # WORKSPACE
+    assert L.digat_clip_adam_step(None, None, None, 1, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, None) == ERR_ARG
+    assert L.digat_clip_adam_step(ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), 0, ws.data_ptr(), 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, None) == 0
+    assert L.digat_clip_adam_step(ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), 1, ws.data_ptr(), 1.0, 1e-3, 0.9, 0.999, 1e-8, 0, None) == ERR_ARG   # step >= 1
+    assert L.digat_click_loss(None, 4, 5, None, None, None) == ERR_ARG
