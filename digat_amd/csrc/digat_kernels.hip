@@ -386,7 +386,11 @@ struct PremadeImage {
 static int launch_split(const float* w0, const float* w1, const float* w2, int nseg, int nsegs, int K, void* wsplit, hipStream_t st,
                         int transposed = 0, int format = 0) {
     if (format != 0 && format != 1) return DIGAT_ERR_ARG;
+#ifdef DIGAT_LAB
+    if (wsplit && wsplit == tl_premade_image && format == 0) return DIGAT_OK;      // (LAB, DIGAT_TRAIN_F16: an fp16x3 image is split over the ready-made one)
+#else
     if (wsplit && wsplit == tl_premade_image) return format == 0 ? DIGAT_OK : DIGAT_ERR_ARG;
+#endif
     const long total = (long)nseg * nsegs * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
