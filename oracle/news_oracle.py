@@ -17,9 +17,12 @@ import torch
 import torch.nn.functional as F
 
 
-def msa_forward(p: Dict[str, torch.Tensor], title_text: torch.Tensor, title_mask: torch.Tensor, head_num: int) -> torch.Tensor:
-    """title_text [T, Lw] int64, title_mask [T, Lw] (0 = padding) -> news representation [T, head_num * d_k]."""
+def msa_forward(p: Dict[str, torch.Tensor], title_text: torch.Tensor, title_mask: torch.Tensor, head_num: int, drop=None) -> torch.Tensor:
+    """title_text [T, Lw] int64, title_mask [T, Lw] (0 = padding) -> news representation [T, head_num * d_k].
+    ``drop`` (train mode): the dropout on the embedded tokens (newsEncoders.py:77), a callable on the [T, Lw, dm] tensor; None = eval."""
     w = p["word_embedding.weight"].index_select(0, title_text.reshape(-1)).view(*title_text.shape, -1)   # :76
+    if drop is not None:
+        w = drop(w)                                                                                      # :77
     T, Lw, _ = w.shape
     q = F.linear(w, p["multiheadSelfattention.W_Q.weight"], p["multiheadSelfattention.W_Q.bias"])       # layers.py:78
     k = F.linear(w, p["multiheadSelfattention.W_K.weight"])                                             # :79 (no bias)

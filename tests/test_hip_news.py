@@ -118,6 +118,29 @@ def test_msa_training_step_matches_reference_autograd(name):
             check_grad_digest(fx, k, p.grad.detach().cpu().numpy(), 2e-4, "grad ")
 
 
+def test_msa_training_with_dropout_live_matches_the_oracle_under_the_same_mask():
+    """The embedding dropout LIVE (newsEncoders.py:77): the library draws its keep bits from the counter hash of (seed, element of the
+    [T Lw, dm] embedded tokens) and applies the backward in the epilogue of the 2 304-row input-gradient product (300 columns in 320-column
+    strips).  The oracle's autograd under the same mask: output and every gradient, the word embedding's included."""
+    from oracle import digat_oracle as O
+    from oracle import news_oracle as N
+    fx, enc, text, mask, R = _train_case("msa_train_default.npz", dropout=0.2)
+    T_, Lw, V, dm, h, dk, att = (int(v) for v in fx["meta"])
+    assert T_ * Lw >= 2048 and dm % 80 != 0
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())           # what MsaFused.forward will draw
+    torch.manual_seed(77)
+    out = enc(text.unsqueeze(0), mask.unsqueeze(0)).squeeze(0)
+    (out * R).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    want = N.msa_forward(p, text.cpu().long(), mask.cpu(), h, drop=lambda w: O.hash_dropout(w.contiguous(), 0.2, seed))
+    (want * R.cpu()).sum().backward()
+    _close(out, want.detach().numpy(), "news representation under dropout", rtol=1e-5, atol=2e-6)
+    for k, q in enc.named_parameters():
+        _close(q.grad, p[k].grad.numpy(), "grad " + k + " under dropout")
+
+
 def test_msa_training_with_dropout_is_reproducible_and_finite():
     def once():
         torch.manual_seed(11)
