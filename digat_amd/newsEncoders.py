@@ -128,7 +128,8 @@ class MsaFused(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         ld = int(L.digat_msa_row_grad_ld(T, Lw, dm))
         row_grad = torch.empty((T * Lw, ld), **f)
-        dWQ, dWK, dWV = (torch.empty((hd, dm), **f) for _ in range(3))
+        dW3 = torch.empty((3, hd, dm), **f)       # one buffer: the library writes its single [3 hd, dm] weight-gradient product in place
+        dWQ, dWK, dWV = dW3[0], dW3[1], dW3[2]
         dbQ, dbV = torch.empty(hd, **f), torch.empty(hd, **f)
         dA1, db1, da2 = torch.empty((att, hd), **f), torch.empty(att, **f), torch.empty(att, **f)
         _lib.check(L.digat_msa_bwd(P, tokens.data_ptr(), mask.data_ptr(), dout.data_ptr(), ctx.p, save.data_ptr(), nsave,
