@@ -422,7 +422,7 @@ int digat_split_jobs(const digat_split_job* jobs, int njobs, void* stream) {
         o.w0 = j.w0; o.w1 = three ? j.w1 : j.w0; o.w2 = three ? j.w2 : j.w0; o.out = (unsigned short*)j.image;
         if (j.layout == 0) { o.nseg = j.rows; o.nsegs = three ? 3 : 1; o.K = j.cols; o.transposed = 0; }
         else { o.nseg = j.cols; o.nsegs = 1; o.K = three ? 3 * j.rows : j.rows; o.transposed = three ? 2 : 1; }
-        const long total = (long)o.nseg * o.nsegs * o.K;
+        const long total = (long)((o.nseg * o.nsegs + 79) / 80) * 80 * ((o.K + 31) / 32) * 4;      // 16-byte slots of the image's three planes / 3
         if (total > most) most = total;
         wsplit_note(j.image, 0);
     }
